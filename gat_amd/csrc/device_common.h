@@ -1,0 +1,48 @@
+// Device-side helpers shared by the gfx950 kernels of libgatmi.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gatmi {
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+// exp(x) for x <= 0 (softmax numerators): one v_exp_f32 after scaling the already-subtracted
+// argument, so the rounding error of the scaling is relative to |x| and not to the logits.
+__device__ __forceinline__ float exp_neg(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+
+__device__ __forceinline__ float leaky(float z, float slope) { return fmaxf(z, z * slope); }
+
+// xor-butterfly sum over `N` adjacent lanes (N power of two <= 64).
+template <int N>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < N; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Counter-based dropout mask: splitmix64 finaliser of (seed, index); keep when the top 24 bits,
+// read as a fraction in [0,1), fall below keep_prob.  The same function is restated on the host
+// by the tests to replay masks.
+__device__ __forceinline__ bool keep_mask(uint64_t seed, uint64_t idx, float keep_prob) {
+    uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const uint32_t r = (uint32_t)(z >> 40);  // 24 bits
+    return (float)r * (1.0f / 16777216.0f) < keep_prob;
+}
+
+__device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
+
+// derivative of ELU written in terms of its OUTPUT y: 1 for y > 0, y + 1 (= exp(x)) otherwise
+__device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
+
+}  // namespace gatmi
+
+#define GATMI_LAUNCH_CHECK(name)                                                         \
+    do {                                                                                 \
+        hipError_t e__ = hipGetLastError();                                              \
+        if (e__ != hipSuccess)                                                           \
+            return gatmi::fail(GATMI_EHIP, "%s: %s", name, hipGetErrorString(e__));      \
+    } while (0)

@@ -1,0 +1,617 @@
+// CSR / CSC graph-attention kernels for gfx950 (MI355X): fused edge-softmax + aggregation forward,
+// per-destination backward, per-source backward.
+//
+// Work decomposition (all three row kernels).  A feature row has hd = H*dp floats; it is covered
+// by G = hd/4 adjacent lanes holding one float4 each, so one 64-lane wave walks 64/G rows at once
+// and every row access is a contiguous 16-byte-per-lane load or store.  Lane `sub` of a group
+// belongs to head sub / LPH (LPH = dp/4 lanes per head).  Rows come as work items sorted by
+// length (longest first), so the row groups of one wave loop about equally long, and rows longer
+// than the chunk size are cut into pieces whose partial results meet in a small merge kernel.
+//
+// Softmax is the online form: running maximum m, denominator s and un-normalised weighted sums,
+// rescaled when the maximum grows; neighbours are taken four at a time so that one rescale
+// factor and four numerators cost five v_exp_f32.
+//
+// The backward pass never revisits the CSR side.  With z_ij = f1_i + f2_j, e_ij = LeakyReLU(z_ij),
+// alpha = softmax_j(e), the gradient of f1 is
+//     df1_i = sum_j alpha_ij (dalpha_ij - c_i) * LeakyReLU'(z_ij),   c_i = sum_j alpha_ij dalpha_ij.
+// Since sum_j alpha_ij (dalpha_ij - c_i) = 0 and LeakyReLU' = slope + (1-slope)*[z>0],
+//     df1_i = (1-slope) * ( <g_i, pos_i> - c_i * q_i ),
+// where pos_i / q_i are the aggregate / coefficient mass over the entries with z_ij > 0, which the
+// forward kernel accumulates next to the full aggregate.  c_i = <g_i, agg_i>.  So the only
+// gather in the backward pass is the per-source one (transposed SpMM + SDDMM over CSC).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "device_common.h"
+
+namespace gatmi {
+
+struct FwdArgs {
+    const int4 *items;
+    int64_t n_items;
+    const int32_t *col;
+    const float *feat, *f1, *f2, *bias, *resid;
+    float *out, *agg, *pos, *lse, *q, *ws;
+    int activation, reduce;
+    float slope, coef_keep, feat_keep;
+    uint64_t seed;
+};
+
+__device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 y) {
+    return make_float4(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z), fmaf(a, x.w, y.w));
+}
+__device__ __forceinline__ float4 f4_scale(float a, float4 x) { return make_float4(a * x.x, a * x.y, a * x.z, a * x.w); }
+__device__ __forceinline__ float4 f4_add(float4 x, float4 y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); }
+__device__ __forceinline__ float dot4(float4 x, float4 y) { return fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, x.w * y.w))); }
+
+constexpr uint64_t kFeatSeedSalt = 0x5DEECE66Dull;
+
+// feature-dropout of one float4 of row j (columns c0..c0+3): utils/layers.py:22
+__device__ __forceinline__ float4 drop_feat(float4 v, uint64_t seed, int64_t j, int hd, int c0, float keep) {
+    const uint64_t base = (uint64_t)j * (uint64_t)hd + (uint64_t)c0;
+    const float inv = 1.0f / keep;
+    v.x = keep_mask(seed ^ kFeatSeedSalt, base + 0, keep) ? v.x * inv : 0.f;
+    v.y = keep_mask(seed ^ kFeatSeedSalt, base + 1, keep) ? v.y * inv : 0.f;
+    v.z = keep_mask(seed ^ kFeatSeedSalt, base + 2, keep) ? v.z * inv : 0.f;
+    v.w = keep_mask(seed ^ kFeatSeedSalt, base + 3, keep) ? v.w * inv : 0.f;
+    return v;
+}
+
+struct RowState {
+    float m, s, q;
+    float4 acc, pos;
+};
+
+// One batch of U neighbours of one row group.
+template <int G, int LPH, int U, bool SAVE, bool DROP>
+__device__ __forceinline__ void fwd_batch(RowState &st, const FwdArgs &a, const int32_t *cp, int64_t epos,
+                                          float f1v, int sub, int head) {
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    int32_t j[U];
+    float z[U];
+    float4 v[U];
+#pragma unroll
+    for (int t = 0; t < U; ++t) j[t] = cp[t];
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        z[t] = f1v + a.f2[(int64_t)j[t] * H + head];
+        v[t] = *reinterpret_cast<const float4 *>(a.feat + (int64_t)j[t] * HD + sub * 4);
+    }
+    float e[U];
+    float mn = st.m;
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        e[t] = leaky(z[t], a.slope);
+        mn = fmaxf(mn, e[t]);
+    }
+    const float sc = exp_neg(st.m - mn);  // 0 on the first batch (m = -inf)
+    st.s *= sc;
+    st.acc = f4_scale(sc, st.acc);
+    if (SAVE) {
+        st.q *= sc;
+        st.pos = f4_scale(sc, st.pos);
+    }
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        const float p = exp_neg(e[t] - mn);
+        st.s += p;
+        float pa = p;
+        float4 vv = v[t];
+        if (DROP) {
+            if (a.coef_keep < 1.f)
+                pa = keep_mask(a.seed, (uint64_t)(epos + t) * H + head, a.coef_keep) ? p / a.coef_keep : 0.f;
+            if (a.feat_keep < 1.f) vv = drop_feat(vv, a.seed, j[t], HD, sub * 4, a.feat_keep);
+        }
+        st.acc = f4_fma(pa, vv, st.acc);
+        if (SAVE) {
+            const bool ps = z[t] > 0.f;
+            st.q += ps ? p : 0.f;
+            st.pos = f4_fma(ps ? pa : 0.f, vv, st.pos);
+        }
+    }
+    st.m = mn;
+}
+
+// Normalise one finished row and write every output of the forward pass.
+template <int G, int LPH, bool SAVE>
+__device__ __forceinline__ void fwd_finish(const RowState &st, const FwdArgs &a, int64_t row, int sub, int head) {
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    const bool empty = !(st.s > 0.f);
+    const float inv = empty ? 0.f : 1.0f / st.s;
+    const float4 ag = f4_scale(inv, st.acc);
+    if (SAVE) {
+        *reinterpret_cast<float4 *>(a.agg + row * HD + sub * 4) = ag;
+        *reinterpret_cast<float4 *>(a.pos + row * HD + sub * 4) = f4_scale(inv, st.pos);
+        if (sub % LPH == 0) {
+            a.lse[row * H + head] = empty ? 0.f : st.m + logf(st.s);
+            a.q[row * H + head] = st.q * inv;
+        }
+    }
+    float4 r = ag;
+    if (a.bias) r = f4_add(r, *reinterpret_cast<const float4 *>(a.bias + sub * 4));
+    if (a.reduce == GATMI_REDUCE_MEAN) {
+        // identity activation only (checked on the host): mean over heads of (agg + bias)
+#pragma unroll
+        for (int o = LPH; o < G; o <<= 1) {
+            r.x += __shfl_xor(r.x, o, 64);
+            r.y += __shfl_xor(r.y, o, 64);
+            r.z += __shfl_xor(r.z, o, 64);
+            r.w += __shfl_xor(r.w, o, 64);
+        }
+        if (sub < LPH) {
+            r = f4_scale(1.0f / H, r);
+            if (a.resid) r = f4_add(r, *reinterpret_cast<const float4 *>(a.resid + row * (4 * LPH) + sub * 4));
+            *reinterpret_cast<float4 *>(a.out + row * (4 * LPH) + sub * 4) = r;
+        }
+        return;
+    }
+    if (a.resid) r = f4_add(r, *reinterpret_cast<const float4 *>(a.resid + row * HD + sub * 4));
+    if (a.activation == GATMI_ACT_ELU) r = make_float4(elu_f(r.x), elu_f(r.y), elu_f(r.z), elu_f(r.w));
+    *reinterpret_cast<float4 *>(a.out + row * HD + sub * 4) = r;
+}
+
+template <int G, int LPH, bool SAVE, bool DROP>
+__global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
+    constexpr int RPW = 64 / G;
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, grp = lane / G;
+    const int head = sub / LPH;
+    const int64_t it = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp;
+    if (it >= a.n_items) return;
+    const int4 item = a.items[it];
+    const int64_t row = item.x;
+    const int len = item.z;
+    const int32_t *cp = a.col + item.y;
+    const float f1v = a.f1[row * H + head];
+
+    RowState st;
+    st.m = -INFINITY;
+    st.s = 0.f;
+    st.q = 0.f;
+    st.acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    st.pos = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 4 <= len; k += 4) fwd_batch<G, LPH, 4, SAVE, DROP>(st, a, cp + k, (int64_t)item.y + k, f1v, sub, head);
+    if (k + 2 <= len) {
+        fwd_batch<G, LPH, 2, SAVE, DROP>(st, a, cp + k, (int64_t)item.y + k, f1v, sub, head);
+        k += 2;
+    }
+    if (k < len) fwd_batch<G, LPH, 1, SAVE, DROP>(st, a, cp + k, (int64_t)item.y + k, f1v, sub, head);
+
+    if (item.w < 0) {
+        fwd_finish<G, LPH, SAVE>(st, a, row, sub, head);
+    } else {
+        // piece of a long row: park the un-normalised state; layout [m H | s H | q H | acc HD | pos HD]
+        float *rec = a.ws + (int64_t)item.w * (3 * H + 2 * HD);
+        if (sub % LPH == 0) {
+            rec[head] = st.m;
+            rec[H + head] = st.s;
+            rec[2 * H + head] = st.q;
+        }
+        *reinterpret_cast<float4 *>(rec + 3 * H + sub * 4) = st.acc;
+        *reinterpret_cast<float4 *>(rec + 3 * H + HD + sub * 4) = st.pos;
+    }
+}
+
+// Combine the pieces of each long row (one row group per split record).
+template <int G, int LPH, bool SAVE>
+__global__ __launch_bounds__(256) void gat_fwd_merge_kernel(FwdArgs a, const int4 *split, int64_t n_split) {
+    constexpr int RPW = 64 / G;
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, grp = lane / G;
+    const int head = sub / LPH;
+    const int64_t r = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp;
+    if (r >= n_split) return;
+    const int4 rec = split[r];
+    RowState st;
+    st.m = -INFINITY;
+    st.s = 0.f;
+    st.q = 0.f;
+    st.acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    st.pos = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < rec.z; ++c) {
+        const float *p = a.ws + (int64_t)(rec.y + c) * (3 * H + 2 * HD);
+        const float pm = p[head], ps = p[H + head], pq = p[2 * H + head];
+        const float4 pa = *reinterpret_cast<const float4 *>(p + 3 * H + sub * 4);
+        const float4 pp = *reinterpret_cast<const float4 *>(p + 3 * H + HD + sub * 4);
+        const float mn = fmaxf(st.m, pm);
+        const float s0 = exp_neg(st.m - mn), s1 = exp_neg(pm - mn);
+        st.s = st.s * s0 + ps * s1;
+        st.q = st.q * s0 + pq * s1;
+        st.acc = f4_fma(s1, pa, f4_scale(s0, st.acc));
+        st.pos = f4_fma(s1, pp, f4_scale(s0, st.pos));
+        st.m = mn;
+    }
+    fwd_finish<G, LPH, SAVE>(st, a, rec.x, sub, head);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, per-destination part
+// ------------------------------------------------------------------------------------------
+struct BwdNodeArgs {
+    int64_t n;
+    const float *dout, *out, *agg, *pos, *q, *f1, *lse;
+    float *g, *stats, *df1, *ws;
+    int activation, reduce;
+    float slope;
+};
+
+constexpr int kNodeBlocks = 1024;  // persistent grid of the per-destination kernel
+
+template <int G, int LPH>
+__global__ __launch_bounds__(256) void gat_bwd_node_kernel(BwdNodeArgs a) {
+    constexpr int RPW = 64 / G;
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    __shared__ float4 red[256];
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, grp = lane / G;
+    const int head = sub / LPH;
+    const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+    float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp; row < a.n; row += stride) {
+        float4 gv;
+        if (a.reduce == GATMI_REDUCE_MEAN) {
+            gv = f4_scale(1.0f / H, *reinterpret_cast<const float4 *>(a.dout + row * (4 * LPH) + (sub % LPH) * 4));
+        } else {
+            gv = *reinterpret_cast<const float4 *>(a.dout + row * HD + sub * 4);
+            if (a.activation == GATMI_ACT_ELU) {
+                const float4 o = *reinterpret_cast<const float4 *>(a.out + row * HD + sub * 4);
+                gv.x *= elu_grad_from_out(o.x);
+                gv.y *= elu_grad_from_out(o.y);
+                gv.z *= elu_grad_from_out(o.z);
+                gv.w *= elu_grad_from_out(o.w);
+            }
+        }
+        const float4 ag = *reinterpret_cast<const float4 *>(a.agg + row * HD + sub * 4);
+        const float4 ps = *reinterpret_cast<const float4 *>(a.pos + row * HD + sub * 4);
+        const float c = group_sum<LPH>(dot4(gv, ag));
+        const float gp = group_sum<LPH>(dot4(gv, ps));
+        *reinterpret_cast<float4 *>(a.g + row * HD + sub * 4) = gv;
+        if (sub % LPH == 0) {
+            const float qv = a.q[row * H + head];
+            a.stats[row * 3 * H + head] = a.f1[row * H + head];
+            a.stats[row * 3 * H + H + head] = a.lse[row * H + head];
+            a.stats[row * 3 * H + 2 * H + head] = c;
+            a.df1[row * H + head] = (1.0f - a.slope) * (gp - c * qv);
+        }
+        gsum = f4_add(gsum, gv);
+    }
+    // column sums of g for dbias: lanes with equal `sub` across the block, fixed order
+    red[threadIdx.x] = gsum;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = threadIdx.x; i < 256; i += G) t = f4_add(t, red[i]);
+        *reinterpret_cast<float4 *>(a.ws + (int64_t)blockIdx.x * HD + threadIdx.x * 4) = t;
+    }
+}
+
+// out[c] = sum over `rows` partial rows of ws[r][c] (fixed order => reproducible)
+__global__ void column_sum_kernel(const float *ws, int rows, int width, float *out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += ws[(int64_t)r * width + c];
+    out[c] = t;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, per-source part (CSC)
+// ------------------------------------------------------------------------------------------
+struct BwdCscArgs {
+    const int4 *items;
+    int64_t n_items;
+    const int32_t *rowidx, *perm;
+    const float *g, *stats, *feat, *f2, *df1, *a1, *a2;
+    float *dfeat, *df2, *ws;
+    float slope, coef_keep, feat_keep;
+    uint64_t seed;
+};
+
+struct SrcState {
+    float4 acc;
+    float df2;
+};
+
+template <int G, int LPH, int U, bool DROP>
+__device__ __forceinline__ void bwd_batch(SrcState &st, const BwdCscArgs &a, const int32_t *rp, int64_t cpos,
+                                          float f2v, float4 whj, int sub, int head) {
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    int32_t i[U];
+    float4 gv[U];
+    float f1v[U], lsev[U], cv[U];
+#pragma unroll
+    for (int t = 0; t < U; ++t) i[t] = rp[t];
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        gv[t] = *reinterpret_cast<const float4 *>(a.g + (int64_t)i[t] * HD + sub * 4);
+        const float *s = a.stats + (int64_t)i[t] * 3 * H + head;
+        f1v[t] = s[0];
+        lsev[t] = s[H];
+        cv[t] = s[2 * H];
+    }
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        const float z = f1v[t] + f2v;
+        const float alpha = exp_neg(leaky(z, a.slope) - lsev[t]);
+        float dalpha = group_sum<LPH>(dot4(gv[t], whj));
+        float aa = alpha;
+        if (DROP) {
+            if (a.coef_keep < 1.f) {
+                const bool kp = keep_mask(a.seed, (uint64_t)a.perm[cpos + t] * H + head, a.coef_keep);
+                const float mk = kp ? 1.0f / a.coef_keep : 0.f;
+                aa = alpha * mk;
+                dalpha *= mk;
+            }
+        }
+        const float dz = alpha * (dalpha - cv[t]) * (z > 0.f ? 1.f : a.slope);
+        st.acc = f4_fma(aa, gv[t], st.acc);
+        st.df2 += dz;
+    }
+}
+
+template <int G, int LPH, bool DROP>
+__device__ __forceinline__ void bwd_finish(const SrcState &st, const BwdCscArgs &a, int64_t j, int sub, int head) {
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    float4 r = st.acc;
+    if (DROP) {
+        if (a.feat_keep < 1.f) r = drop_feat(r, a.seed, j, HD, sub * 4, a.feat_keep);
+    }
+    if (a.a1) {
+        const float d1 = a.df1[j * H + head];
+        r = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + sub * 4), r);
+        r = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + sub * 4), r);
+    }
+    *reinterpret_cast<float4 *>(a.dfeat + j * HD + sub * 4) = r;
+    if (sub % LPH == 0) a.df2[j * H + head] = st.df2;
+}
+
+template <int G, int LPH, bool DROP>
+__global__ __launch_bounds__(256) void gat_bwd_csc_kernel(BwdCscArgs a) {
+    constexpr int RPW = 64 / G;
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, grp = lane / G;
+    const int head = sub / LPH;
+    const int64_t it = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp;
+    if (it >= a.n_items) return;
+    const int4 item = a.items[it];
+    const int64_t j = item.x;
+    const int len = item.z;
+    const int32_t *rp = a.rowidx + item.y;
+    const float f2v = a.f2[j * H + head];
+    float4 whj = *reinterpret_cast<const float4 *>(a.feat + j * HD + sub * 4);
+    if (DROP) {
+        if (a.feat_keep < 1.f) whj = drop_feat(whj, a.seed, j, HD, sub * 4, a.feat_keep);
+    }
+    SrcState st;
+    st.acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    st.df2 = 0.f;
+    int k = 0;
+    for (; k + 4 <= len; k += 4) bwd_batch<G, LPH, 4, DROP>(st, a, rp + k, (int64_t)item.y + k, f2v, whj, sub, head);
+    if (k + 2 <= len) {
+        bwd_batch<G, LPH, 2, DROP>(st, a, rp + k, (int64_t)item.y + k, f2v, whj, sub, head);
+        k += 2;
+    }
+    if (k < len) bwd_batch<G, LPH, 1, DROP>(st, a, rp + k, (int64_t)item.y + k, f2v, whj, sub, head);
+    if (item.w < 0) {
+        bwd_finish<G, LPH, DROP>(st, a, j, sub, head);
+    } else {
+        float *rec = a.ws + (int64_t)item.w * (H + HD);  // [df2 H | acc HD]
+        if (sub % LPH == 0) rec[head] = st.df2;
+        *reinterpret_cast<float4 *>(rec + H + sub * 4) = st.acc;
+    }
+}
+
+template <int G, int LPH, bool DROP>
+__global__ __launch_bounds__(256) void gat_bwd_merge_kernel(BwdCscArgs a, const int4 *split, int64_t n_split) {
+    constexpr int RPW = 64 / G;
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, grp = lane / G;
+    const int head = sub / LPH;
+    const int64_t r = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp;
+    if (r >= n_split) return;
+    const int4 rec = split[r];
+    SrcState st;
+    st.acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    st.df2 = 0.f;
+    for (int c = 0; c < rec.z; ++c) {
+        const float *p = a.ws + (int64_t)(rec.y + c) * (H + HD);
+        st.df2 += p[head];
+        st.acc = f4_add(st.acc, *reinterpret_cast<const float4 *>(p + H + sub * 4));
+    }
+    bwd_finish<G, LPH, DROP>(st, a, rec.x, sub, head);
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side dispatch over (G, LPH)
+// ------------------------------------------------------------------------------------------
+static inline unsigned blocks_for(int64_t n_groups, int G) {
+    const int64_t per_block = 4 * (64 / G);
+    return (unsigned)((n_groups + per_block - 1) / per_block);
+}
+
+#define GATMI_FOR_SHAPES(X) \
+    X(1, 1) X(2, 1) X(2, 2) X(4, 1) X(4, 2) X(4, 4) X(8, 1) X(8, 2) X(8, 4) X(8, 8) \
+    X(16, 1) X(16, 2) X(16, 4) X(16, 8) X(16, 16) X(32, 2) X(32, 4) X(32, 8) X(32, 16) X(32, 32) \
+    X(64, 2) X(64, 4) X(64, 8) X(64, 16) X(64, 32) X(64, 64)
+
+template <int G, int LPH>
+static int launch_fwd(const FwdArgs &a, const int4 *split, int64_t n_split, bool save, bool drop, hipStream_t st) {
+    const unsigned nb = blocks_for(a.n_items, G);
+    if (nb) {
+        if (save && drop) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, true, true>), dim3(nb), dim3(256), 0, st, a);
+        else if (save) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, true, false>), dim3(nb), dim3(256), 0, st, a);
+        else if (drop) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, false, true>), dim3(nb), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, false, false>), dim3(nb), dim3(256), 0, st, a);
+        GATMI_LAUNCH_CHECK("gat_fwd");
+    }
+    if (n_split > 0) {
+        const unsigned mb = blocks_for(n_split, G);
+        if (save) hipLaunchKernelGGL((gat_fwd_merge_kernel<G, LPH, true>), dim3(mb), dim3(256), 0, st, a, split, n_split);
+        else hipLaunchKernelGGL((gat_fwd_merge_kernel<G, LPH, false>), dim3(mb), dim3(256), 0, st, a, split, n_split);
+        GATMI_LAUNCH_CHECK("gat_fwd_merge");
+    }
+    return GATMI_OK;
+}
+
+template <int G, int LPH>
+static int launch_bwd_node(const BwdNodeArgs &a, float *dbias, hipStream_t st) {
+    constexpr int HD = 4 * G;
+    const int64_t per_block = 4 * (64 / G);
+    const unsigned nb = (unsigned)std::min<int64_t>(kNodeBlocks, std::max<int64_t>(1, (a.n + per_block - 1) / per_block));
+    hipLaunchKernelGGL((gat_bwd_node_kernel<G, LPH>), dim3(nb), dim3(256), 0, st, a);
+    GATMI_LAUNCH_CHECK("gat_bwd_node");
+    if (dbias) {
+        hipLaunchKernelGGL(column_sum_kernel, dim3((HD + 63) / 64), dim3(64), 0, st, a.ws, (int)nb, HD, dbias);
+        GATMI_LAUNCH_CHECK("gat_bwd_node dbias");
+    }
+    return GATMI_OK;
+}
+
+template <int G, int LPH>
+static int launch_bwd_csc(const BwdCscArgs &a, const int4 *split, int64_t n_split, bool drop, hipStream_t st) {
+    const unsigned nb = blocks_for(a.n_items, G);
+    if (nb) {
+        if (drop) hipLaunchKernelGGL((gat_bwd_csc_kernel<G, LPH, true>), dim3(nb), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gat_bwd_csc_kernel<G, LPH, false>), dim3(nb), dim3(256), 0, st, a);
+        GATMI_LAUNCH_CHECK("gat_bwd_csc");
+    }
+    if (n_split > 0) {
+        const unsigned mb = blocks_for(n_split, G);
+        if (drop) hipLaunchKernelGGL((gat_bwd_merge_kernel<G, LPH, true>), dim3(mb), dim3(256), 0, st, a, split, n_split);
+        else hipLaunchKernelGGL((gat_bwd_merge_kernel<G, LPH, false>), dim3(mb), dim3(256), 0, st, a, split, n_split);
+        GATMI_LAUNCH_CHECK("gat_bwd_merge");
+    }
+    return GATMI_OK;
+}
+
+}  // namespace gatmi
+
+using namespace gatmi;
+
+extern "C" size_t gatmi_gat_fwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp) {
+    if (n_slots <= 0) return 0;
+    return (size_t)n_slots * (size_t)(3 * H + 2 * H * dp);
+}
+
+extern "C" int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
+                             const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
+                             const int32_t *col, const float *feat, const float *f1, const float *f2,
+                             const float *bias, const float *resid, int32_t activation, int32_t reduce,
+                             float slope, float coef_keep, float feat_keep, uint64_t seed,
+                             float *out, float *agg, float *pos, float *lse, float *q,
+                             float *ws, void *stream) {
+    int G, LPH;
+    int rc = check_shape(H, dp, &G, &LPH);
+    if (rc) return rc;
+    GATMI_REQUIRE(n_dst >= 0 && n_items >= 0 && n_split >= 0, GATMI_EINVAL, "gat_fwd: negative size");
+    if (n_dst == 0 || n_items == 0) return GATMI_OK;
+    GATMI_REQUIRE(items && feat && f1 && f2 && out, GATMI_EINVAL, "gat_fwd: null pointer");
+    GATMI_REQUIRE(n_items >= n_dst, GATMI_EINVAL, "gat_fwd: %lld work items for %lld rows (every row needs an item)", (long long)n_items, (long long)n_dst);
+    GATMI_REQUIRE(n_split == 0 || (split && ws), GATMI_EINVAL, "gat_fwd: split rows need `split` and `ws`");
+    GATMI_REQUIRE(activation == GATMI_ACT_IDENTITY || activation == GATMI_ACT_ELU, GATMI_EUNSUPPORTED, "gat_fwd: activation %d", activation);
+    GATMI_REQUIRE(reduce == GATMI_REDUCE_CONCAT || (reduce == GATMI_REDUCE_MEAN && activation == GATMI_ACT_IDENTITY), GATMI_EUNSUPPORTED,
+                  "gat_fwd: reduce %d with activation %d (mean over heads needs the identity activation)", reduce, activation);
+    GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "gat_fwd: keep probabilities must be in (0,1]");
+    const bool save = agg || pos || lse || q;
+    GATMI_REQUIRE(!save || (agg && pos && lse && q), GATMI_EINVAL, "gat_fwd: agg, pos, lse, q must be given together");
+    GATMI_REQUIRE_ALIGNED(items); GATMI_REQUIRE_ALIGNED(split); GATMI_REQUIRE_ALIGNED(feat); GATMI_REQUIRE_ALIGNED(bias);
+    GATMI_REQUIRE_ALIGNED(resid); GATMI_REQUIRE_ALIGNED(out); GATMI_REQUIRE_ALIGNED(agg); GATMI_REQUIRE_ALIGNED(pos); GATMI_REQUIRE_ALIGNED(ws);
+    FwdArgs a;
+    a.items = reinterpret_cast<const int4 *>(items);
+    a.n_items = n_items;
+    a.col = col; a.feat = feat; a.f1 = f1; a.f2 = f2; a.bias = bias; a.resid = resid;
+    a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.ws = ws;
+    a.activation = activation; a.reduce = reduce;
+    a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
+    const bool drop = coef_keep < 1.f || feat_keep < 1.f;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int4 *sp = reinterpret_cast<const int4 *>(split);
+#define X(g, l) if (G == g && LPH == l) return launch_fwd<g, l>(a, sp, n_split, save, drop, st);
+    GATMI_FOR_SHAPES(X)
+#undef X
+    return fail(GATMI_EUNSUPPORTED, "gat_fwd: no kernel for H=%d dp=%d", H, dp);
+}
+
+extern "C" size_t gatmi_gat_bwd_node_ws_floats(int32_t H, int32_t dp) { return (size_t)kNodeBlocks * (size_t)H * dp; }
+
+extern "C" int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
+                                  const float *dout, const float *out, const float *agg, const float *pos,
+                                  const float *q, const float *f1, const float *lse,
+                                  int32_t activation, int32_t reduce, float slope,
+                                  float *g, float *stats, float *df1, float *dbias, float *ws, void *stream) {
+    int G, LPH;
+    int rc = check_shape(H, dp, &G, &LPH);
+    if (rc) return rc;
+    GATMI_REQUIRE(n_dst >= 0, GATMI_EINVAL, "gat_bwd_node: negative size");
+    GATMI_REQUIRE(dout && agg && pos && q && f1 && lse && g && stats && df1 && ws, GATMI_EINVAL, "gat_bwd_node: null pointer");
+    GATMI_REQUIRE(activation == GATMI_ACT_IDENTITY || (activation == GATMI_ACT_ELU && out), GATMI_EUNSUPPORTED, "gat_bwd_node: activation %d (ELU needs `out`)", activation);
+    GATMI_REQUIRE(reduce == GATMI_REDUCE_CONCAT || (reduce == GATMI_REDUCE_MEAN && activation == GATMI_ACT_IDENTITY), GATMI_EUNSUPPORTED, "gat_bwd_node: reduce %d", reduce);
+    GATMI_REQUIRE_ALIGNED(dout); GATMI_REQUIRE_ALIGNED(out); GATMI_REQUIRE_ALIGNED(agg); GATMI_REQUIRE_ALIGNED(pos);
+    GATMI_REQUIRE_ALIGNED(g); GATMI_REQUIRE_ALIGNED(ws);
+    BwdNodeArgs a;
+    a.n = n_dst; a.dout = dout; a.out = out; a.agg = agg; a.pos = pos; a.q = q; a.f1 = f1; a.lse = lse;
+    a.g = g; a.stats = stats; a.df1 = df1; a.ws = ws;
+    a.activation = activation; a.reduce = reduce; a.slope = slope;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define X(gg, l) if (G == gg && LPH == l) return launch_bwd_node<gg, l>(a, dbias, st);
+    GATMI_FOR_SHAPES(X)
+#undef X
+    return fail(GATMI_EUNSUPPORTED, "gat_bwd_node: no kernel for H=%d dp=%d", H, dp);
+}
+
+extern "C" size_t gatmi_gat_bwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp) {
+    if (n_slots <= 0) return 0;
+    return (size_t)n_slots * (size_t)(H + H * dp);
+}
+
+extern "C" int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
+                                 const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
+                                 const int32_t *rowidx, const int32_t *perm,
+                                 const float *g, const float *stats, const float *feat, const float *f2,
+                                 const float *df1, const float *a1, const float *a2,
+                                 float slope, float coef_keep, float feat_keep, uint64_t seed,
+                                 float *dfeat, float *df2, float *ws, void *stream) {
+    int G, LPH;
+    int rc = check_shape(H, dp, &G, &LPH);
+    if (rc) return rc;
+    GATMI_REQUIRE(n_src >= 0 && n_items >= 0 && n_split >= 0, GATMI_EINVAL, "gat_bwd_csc: negative size");
+    if (n_src == 0 || n_items == 0) return GATMI_OK;
+    GATMI_REQUIRE(items && g && stats && feat && f2 && dfeat && df2, GATMI_EINVAL, "gat_bwd_csc: null pointer");
+    GATMI_REQUIRE(n_items >= n_src, GATMI_EINVAL, "gat_bwd_csc: %lld work items for %lld rows", (long long)n_items, (long long)n_src);
+    GATMI_REQUIRE((a1 == nullptr) == (a2 == nullptr) && (!a1 || df1), GATMI_EINVAL, "gat_bwd_csc: a1, a2 and df1 go together");
+    GATMI_REQUIRE(n_split == 0 || (split && ws), GATMI_EINVAL, "gat_bwd_csc: split rows need `split` and `ws`");
+    GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "gat_bwd_csc: keep probabilities must be in (0,1]");
+    GATMI_REQUIRE(coef_keep >= 1.f || perm, GATMI_EINVAL, "gat_bwd_csc: coefficient dropout needs `perm`");
+    GATMI_REQUIRE_ALIGNED(items); GATMI_REQUIRE_ALIGNED(split); GATMI_REQUIRE_ALIGNED(g); GATMI_REQUIRE_ALIGNED(feat);
+    GATMI_REQUIRE_ALIGNED(a1); GATMI_REQUIRE_ALIGNED(a2); GATMI_REQUIRE_ALIGNED(dfeat); GATMI_REQUIRE_ALIGNED(ws);
+    BwdCscArgs a;
+    a.items = reinterpret_cast<const int4 *>(items);
+    a.n_items = n_items; a.rowidx = rowidx; a.perm = perm;
+    a.g = g; a.stats = stats; a.feat = feat; a.f2 = f2; a.df1 = df1; a.a1 = a1; a.a2 = a2;
+    a.dfeat = dfeat; a.df2 = df2; a.ws = ws;
+    a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
+    const bool drop = coef_keep < 1.f || feat_keep < 1.f;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int4 *sp = reinterpret_cast<const int4 *>(split);
+#define X(gg, l) if (G == gg && LPH == l) return launch_bwd_csc<gg, l>(a, sp, n_split, drop, st);
+    GATMI_FOR_SHAPES(X)
+#undef X
+    return fail(GATMI_EUNSUPPORTED, "gat_bwd_csc: no kernel for H=%d dp=%d", H, dp);
+}

@@ -1,0 +1,68 @@
+// Halo exchange helpers for the row-partitioned multi-GPU layer: gather the feature rows a peer
+// asked for into a contiguous send buffer, and add returned gradient rows into their owners.
+// The exchange itself (all-to-all over RCCL / xGMI) is issued by the caller between the two.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "device_common.h"
+
+namespace gatmi {
+
+// rows of `width` floats (multiple of 4): each float4 of a row is one lane's load + store
+__global__ __launch_bounds__(256) void halo_pack_kernel(const float *src, const int64_t *idx, int64_t n_idx, int w4,
+                                                         float *dst) {
+    const int64_t total = n_idx * w4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t k = e / w4;
+        const int c = (int)(e % w4);
+        reinterpret_cast<float4 *>(dst)[e] = reinterpret_cast<const float4 *>(src)[idx[k] * w4 + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void halo_unpack_add_kernel(const float *src, const int64_t *idx, int64_t n_idx,
+                                                               int w4, float *dst) {
+    const int64_t total = n_idx * w4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t k = e / w4;
+        const int c = (int)(e % w4);
+        float4 *d = reinterpret_cast<float4 *>(dst) + idx[k] * w4 + c;
+        const float4 s = reinterpret_cast<const float4 *>(src)[e];
+        float4 v = *d;
+        v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        *d = v;
+    }
+}
+
+}  // namespace gatmi
+
+using namespace gatmi;
+
+static int halo_common(const float *src, const int64_t *idx, int64_t n_idx, int32_t width, float *dst, const char *name) {
+    GATMI_REQUIRE(n_idx >= 0 && width > 0 && width % 4 == 0, GATMI_EINVAL, "%s: width=%d must be a positive multiple of 4", name, width);
+    GATMI_REQUIRE(n_idx == 0 || (src && idx && dst), GATMI_EINVAL, "%s: null pointer", name);
+    GATMI_REQUIRE_ALIGNED(src);
+    GATMI_REQUIRE_ALIGNED(dst);
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_halo_pack(const float *src, const int64_t *idx, int64_t n_idx, int32_t width, float *dst, void *stream) {
+    int rc = halo_common(src, idx, n_idx, width, dst, "halo_pack");
+    if (rc || n_idx == 0) return rc;
+    const int64_t total = n_idx * (width / 4);
+    const unsigned nb = (unsigned)std::min<int64_t>(4096, (total + 255) / 256);
+    hipLaunchKernelGGL(halo_pack_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, idx, n_idx, width / 4, dst);
+    GATMI_LAUNCH_CHECK("halo_pack");
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_halo_unpack_add(const float *src, const int64_t *idx, int64_t n_idx, int32_t width, float *dst, void *stream) {
+    int rc = halo_common(src, idx, n_idx, width, dst, "halo_unpack_add");
+    if (rc || n_idx == 0) return rc;
+    const int64_t total = n_idx * (width / 4);
+    const unsigned nb = (unsigned)std::min<int64_t>(4096, (total + 255) / 256);
+    hipLaunchKernelGGL(halo_unpack_add_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, idx, n_idx, width / 4, dst);
+    GATMI_LAUNCH_CHECK("halo_unpack_add");
+    return GATMI_OK;
+}

@@ -1,0 +1,507 @@
+// Feature projection kernels for gfx950: Wh = X.W with the attention-logit halves fused into the
+// epilogue, and the gradients dW = X^T.dWh, dX = dWh.W^T, da1/da2/db1/db2.
+//
+// All three contractions are "tall and skinny": one dimension is the node count (millions), the
+// other two are small (f_in ~ 10^2..10^3, hd <= 256).  They are HBM-bound streams of X / Wh / dWh
+// rows with a small operand kept on chip, and run on the exact-fp32 matrix instruction
+// v_mfma_f32_16x16x4_f32 (lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; the 16x16 result has
+// column l&15 and rows 4*(l>>4)+r in register r).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "device_common.h"
+
+namespace gatmi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTileRows = 128;  // rows of C per block (4 waves x 2 M-tiles of 16)
+constexpr int kTileCols = 64;   // columns of C per block (4 N-tiles of 16)
+constexpr int kChunkK = 64;     // K extent of the B slab staged in LDS
+constexpr int kLdB = 68;        // LDS row stride of B and C tiles: 4*68 mod 32 = 16 => the two
+                                // k-rows read by one 32-lane half land on disjoint banks
+
+struct GemmArgs {
+    const float *A;   // [n, K], row stride lda
+    int64_t n;
+    int K;
+    int64_t lda;
+    const float *B;   // element (k, c) at B[k*sbk + c*sbc]
+    int64_t sbk, sbc;
+    int Nc;
+    float *C;         // [n, Nc], row stride ldc
+    int64_t ldc;
+    int accumulate;
+    const float *cbias;  // [Nc] added to C, or null
+    // fused logit halves (only when the whole row is inside one column tile)
+    const float *a1, *a2, *b1, *b2;
+    float *f1, *f2;
+    int H, LPH;
+};
+
+// C[n, Nc] = A[n, K] . B[K, Nc]; B small.  VEC: A rows are 16-byte aligned and K % 4 == 0.
+template <bool VEC>
+__global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[kTileRows * kLdB];  // B slab (64 rows), later the C tile (128 rows)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * kTileRows;
+    const int col0 = blockIdx.y * kTileCols;
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int64_t arow[2];
+    bool rok[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        arow[mt] = row0 + wave * 32 + mt * 16 + m;
+        rok[mt] = arow[mt] < g.n;
+    }
+
+    for (int kc = 0; kc < g.K; kc += kChunkK) {
+        __syncthreads();
+        // stage B[kc .. kc+64) x [col0 .. col0+64), zero-filled outside
+        if (g.sbc == 1) {
+            for (int e = threadIdx.x; e < kChunkK * kTileCols; e += 256) {
+                const int kk = e >> 6, c = e & 63;
+                const bool ok = (kc + kk < g.K) && (col0 + c < g.Nc);
+                lds[kk * kLdB + c] = ok ? g.B[(int64_t)(kc + kk) * g.sbk + (col0 + c)] : 0.f;
+            }
+        } else {
+            for (int e = threadIdx.x; e < kChunkK * kTileCols; e += 256) {
+                const int c = e >> 6, kk = e & 63;
+                const bool ok = (kc + kk < g.K) && (col0 + c < g.Nc);
+                lds[kk * kLdB + c] = ok ? g.B[(int64_t)(kc + kk) * g.sbk + (int64_t)(col0 + c) * g.sbc] : 0.f;
+            }
+        }
+        __syncthreads();
+        // A fragments of this slab: lane (m, kq) takes k = kc + 16*s + 4*kq + t, t = 0..3
+        float a[4][2][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int k = kc + 16 * s + 4 * kq;
+                if (VEC) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (rok[mt] && k < g.K) v = *reinterpret_cast<const float4 *>(g.A + arow[mt] * g.lda + k);
+                    a[s][mt][0] = v.x; a[s][mt][1] = v.y; a[s][mt][2] = v.z; a[s][mt][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a[s][mt][t] = (rok[mt] && k + t < g.K) ? g.A[arow[mt] * g.lda + k + t] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float *brow = lds + (16 * s + 4 * kq + t) * kLdB + m;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float b = brow[16 * nt];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][mt][t], b, acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // C tile through LDS so that global stores are whole-row float4 runs
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[(wave * 32 + mt * 16 + 4 * kq + r) * kLdB + 16 * nt + m] = acc[mt][nt][r];
+    __syncthreads();
+
+    const int c4 = threadIdx.x & 15;
+    const int col = col0 + 4 * c4;
+    const bool vec_store = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.cbias) {
+        if (col + 0 < g.Nc) bv.x = g.cbias[col + 0];
+        if (col + 1 < g.Nc) bv.y = g.cbias[col + 1];
+        if (col + 2 < g.Nc) bv.z = g.cbias[col + 2];
+        if (col + 3 < g.Nc) bv.w = g.cbias[col + 3];
+    }
+    float4 a1v = make_float4(0.f, 0.f, 0.f, 0.f), a2v = a1v;
+    int head = 0;
+    if (g.f1) {  // whole row inside this tile: Nc <= 64, columns padded to a multiple of 4
+        if (col < g.Nc) {
+            a1v = *reinterpret_cast<const float4 *>(g.a1 + col);
+            a2v = *reinterpret_cast<const float4 *>(g.a2 + col);
+        }
+        head = c4 / g.LPH;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int rl = (threadIdx.x >> 4) + 16 * i;
+        const int64_t row = row0 + rl;
+        float4 v = *reinterpret_cast<const float4 *>(lds + rl * kLdB + 4 * c4);
+        if (g.f1) {
+            float p1 = v.x * a1v.x + v.y * a1v.y + v.z * a1v.z + v.w * a1v.w;
+            float p2 = v.x * a2v.x + v.y * a2v.y + v.z * a2v.z + v.w * a2v.w;
+            for (int o = 1; o < g.LPH; o <<= 1) {
+                p1 += __shfl_xor(p1, o, 64);
+                p2 += __shfl_xor(p2, o, 64);
+            }
+            if (row < g.n && col < g.Nc && (c4 % g.LPH) == 0) {
+                g.f1[row * g.H + head] = p1 + g.b1[head];
+                g.f2[row * g.H + head] = p2 + g.b2[head];
+            }
+        }
+        if (row >= g.n || col >= g.Nc) continue;
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        float *cp = g.C + row * g.ldc + col;
+        if (vec_store && col + 3 < g.Nc) {
+            if (g.accumulate) {
+                const float4 o = *reinterpret_cast<const float4 *>(cp);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4 *>(cp) = v;
+        } else {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            for (int t = 0; t < 4 && col + t < g.Nc; ++t) cp[t] = g.accumulate ? cp[t] + vv[t] : vv[t];
+        }
+    }
+}
+
+// f1/f2 from finished Wh rows when hd > 64 (a row spans several column tiles).
+template <int G>
+__global__ __launch_bounds__(256) void logit_halves_kernel(const float *Wh, int64_t n, int H, int LPH,
+                                                            const float *a1, const float *a2, const float *b1,
+                                                            const float *b2, float *f1, float *f2) {
+    constexpr int RPW = 64 / G;
+    constexpr int HD = 4 * G;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, grp = lane / G;
+    const int head = sub / LPH;
+    const float4 a1v = *reinterpret_cast<const float4 *>(a1 + sub * 4);
+    const float4 a2v = *reinterpret_cast<const float4 *>(a2 + sub * 4);
+    const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+    for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp; row < n; row += stride) {
+        const float4 v = *reinterpret_cast<const float4 *>(Wh + row * HD + sub * 4);
+        float p1 = v.x * a1v.x + v.y * a1v.y + v.z * a1v.z + v.w * a1v.w;
+        float p2 = v.x * a2v.x + v.y * a2v.y + v.z * a2v.z + v.w * a2v.w;
+        for (int o = 1; o < LPH; o <<= 1) {
+            p1 += __shfl_xor(p1, o, 64);
+            p2 += __shfl_xor(p2, o, 64);
+        }
+        if (sub % LPH == 0) {
+            f1[row * H + head] = p1 + b1[head];
+            f2[row * H + head] = p2 + b2[head];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// dW = X^T . dWh, reduced over nodes.  Block (bx, by): node chunks bx, bx+gridDim.x, ...;
+// feature rows [by*16*MT, +16*MT).  Each wave keeps an [16*MT x 16*NT] partial in registers.
+// ------------------------------------------------------------------------------------------
+constexpr int kRedBlocks = 512;
+constexpr int kNodeChunk = 64;
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void xt_gemm_kernel(const float *X, int64_t n, int F, int64_t ldx,
+                                                       const float *dY, int hd, float *ws) {
+    __shared__ float red[MT * 16 * (NT * 16 + 1)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int f0 = blockIdx.y * MT * 16;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int fcol[MT];
+    bool fok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        fcol[mt] = f0 + 16 * mt + m;
+        fok[mt] = fcol[mt] < F;
+        if (!fok[mt]) fcol[mt] = 0;
+    }
+    int ycol[NT];
+    bool yok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        ycol[nt] = 16 * nt + m;
+        yok[nt] = ycol[nt] < hd;
+        if (!yok[nt]) ycol[nt] = 0;
+    }
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t wave_stride = (int64_t)gridDim.x * 4 * kNodeChunk;
+    for (int64_t base = wave_id * kNodeChunk; base < n; base += wave_stride) {
+#pragma unroll 4
+        for (int s = 0; s < kNodeChunk / 4; ++s) {
+            const int64_t node = base + 4 * s + kq;
+            const bool nok = node < n;
+            float a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = (nok && fok[mt]) ? X[node * ldx + fcol[mt]] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = (nok && yok[nt]) ? dY[node * hd + ycol[nt]] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    // sum the four waves in a fixed order, then park the block's partial
+    constexpr int LD = NT * 16 + 1;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float *p = red + (16 * mt + 4 * kq + r) * LD + 16 * nt + m;
+                        *p = (w == 0) ? acc[mt][nt][r] : *p + acc[mt][nt][r];
+                    }
+        }
+        __syncthreads();
+    }
+    // ws layout: [gridDim.x][F_pad = gridDim.y*16*MT][NT*16]
+    const int Fp = gridDim.y * MT * 16;
+    float *out = ws + ((int64_t)blockIdx.x * Fp + f0) * (NT * 16);
+    for (int e = threadIdx.x; e < MT * 16 * NT * 16; e += 256) {
+        const int r = e / (NT * 16), c = e % (NT * 16);
+        out[(int64_t)r * (NT * 16) + c] = red[r * LD + c];
+    }
+}
+
+// dW[f][c] = sum_b ws[b][f][c]   (f < F, c < hd; ws rows are NT16 wide)
+__global__ void reduce_dw_kernel(const float *ws, int nblocks, int Fp, int NT16, int F, int hd, float *dW) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= F * hd) return;
+    const int f = e / hd, c = e % hd;
+    float t = 0.f;
+    for (int b = 0; b < nblocks; ++b) t += ws[((int64_t)b * Fp + f) * NT16 + c];
+    dW[e] = t;
+}
+
+// da1 = sum_i df1[i,h] Wh[i,h,:], da2 likewise with df2, db1 = sum_i df1, db2 = sum_i df2.
+template <int G>
+__global__ __launch_bounds__(256) void attn_param_grad_kernel(const float *Wh, const float *df1, const float *df2,
+                                                               int64_t n, int H, int LPH, float *ws) {
+    constexpr int RPW = 64 / G;
+    constexpr int HD = 4 * G;
+    __shared__ float4 red[256];
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, grp = lane / G;
+    const int head = sub / LPH;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    float t1 = 0.f, t2 = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+    for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp; row < n; row += stride) {
+        const float4 v = *reinterpret_cast<const float4 *>(Wh + row * HD + sub * 4);
+        const float d1 = df1[row * H + head], d2 = df2[row * H + head];
+        s1.x += d1 * v.x; s1.y += d1 * v.y; s1.z += d1 * v.z; s1.w += d1 * v.w;
+        s2.x += d2 * v.x; s2.y += d2 * v.y; s2.z += d2 * v.z; s2.w += d2 * v.w;
+        t1 += d1;
+        t2 += d2;
+    }
+    // block partial layout in ws: [da1 HD | da2 HD | db1 H | db2 H]
+    float *out = ws + (int64_t)blockIdx.x * (2 * HD + 2 * H);
+    for (int pass = 0; pass < 3; ++pass) {
+        red[threadIdx.x] = pass == 0 ? s1 : (pass == 1 ? s2 : make_float4(t1, t2, 0.f, 0.f));
+        __syncthreads();
+        if (threadIdx.x < G) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = threadIdx.x; i < 256; i += G) t = make_float4(t.x + red[i].x, t.y + red[i].y, t.z + red[i].z, t.w + red[i].w);
+            if (pass < 2) *reinterpret_cast<float4 *>(out + pass * HD + threadIdx.x * 4) = t;
+            else if (threadIdx.x % LPH == 0) {
+                out[2 * HD + threadIdx.x / LPH] = t.x;
+                out[2 * HD + H + threadIdx.x / LPH] = t.y;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void reduce_attn_param_kernel(const float *ws, int nblocks, int hd, int H, float *da1, float *da2,
+                                         float *db1, float *db2) {
+    const int width = 2 * hd + 2 * H;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    float t = 0.f;
+    for (int b = 0; b < nblocks; ++b) t += ws[(int64_t)b * width + c];
+    if (c < hd) da1[c] = t;
+    else if (c < 2 * hd) da2[c - hd] = t;
+    else if (c < 2 * hd + H) db1[c - 2 * hd] = t;
+    else db2[c - 2 * hd - H] = t;
+}
+
+static int launch_tall_gemm(const GemmArgs &g, hipStream_t st, const char *name) {
+    if (g.n == 0 || g.Nc == 0) return GATMI_OK;
+    const dim3 grid((unsigned)((g.n + kTileRows - 1) / kTileRows), (unsigned)((g.Nc + kTileCols - 1) / kTileCols));
+    const bool vec = (g.lda % 4 == 0) && (g.K % 4 == 0) && aligned16(g.A);
+    if (vec) hipLaunchKernelGGL(tall_gemm_kernel<true>, grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(tall_gemm_kernel<false>, grid, dim3(256), 0, st, g);
+    GATMI_LAUNCH_CHECK(name);
+    return GATMI_OK;
+}
+
+template <int G>
+static int launch_logit_halves(const float *Wh, int64_t n, int H, int LPH, const float *a1, const float *a2,
+                               const float *b1, const float *b2, float *f1, float *f2, hipStream_t st) {
+    const int64_t per_block = 4 * (64 / G);
+    const unsigned nb = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(1, (n + per_block - 1) / per_block));
+    hipLaunchKernelGGL(logit_halves_kernel<G>, dim3(nb), dim3(256), 0, st, Wh, n, H, LPH, a1, a2, b1, b2, f1, f2);
+    GATMI_LAUNCH_CHECK("logit_halves");
+    return GATMI_OK;
+}
+
+template <int G>
+static int launch_attn_param_grad(const float *Wh, const float *df1, const float *df2, int64_t n, int H, int LPH,
+                                  float *ws, float *da1, float *da2, float *db1, float *db2, hipStream_t st) {
+    const int64_t per_block = 4 * (64 / G);
+    const unsigned nb = (unsigned)std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + per_block - 1) / per_block));
+    hipLaunchKernelGGL(attn_param_grad_kernel<G>, dim3(nb), dim3(256), 0, st, Wh, df1, df2, n, H, LPH, ws);
+    GATMI_LAUNCH_CHECK("attn_param_grad");
+    const int width = 2 * 4 * G + 2 * H;
+    hipLaunchKernelGGL(reduce_attn_param_kernel, dim3((width + 63) / 64), dim3(64), 0, st, ws, (int)nb, 4 * G, H, da1, da2, db1, db2);
+    GATMI_LAUNCH_CHECK("reduce_attn_param");
+    return GATMI_OK;
+}
+
+template <int MT>
+static int launch_xt_gemm(const float *X, int64_t n, int F, int64_t ldx, const float *dY, int hd, float *ws,
+                          float *dW, hipStream_t st) {
+    const int NT = (hd + 15) / 16;
+    const unsigned gy = (unsigned)((F + MT * 16 - 1) / (MT * 16));
+    const unsigned gx = (unsigned)std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 4 * kNodeChunk - 1) / (4 * kNodeChunk)));
+    const dim3 grid(gx, gy);
+    int nt_pad;
+    if (NT <= 1) { nt_pad = 1; hipLaunchKernelGGL((xt_gemm_kernel<MT, 1>), grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws); }
+    else if (NT <= 2) { nt_pad = 2; hipLaunchKernelGGL((xt_gemm_kernel<MT, 2>), grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws); }
+    else { nt_pad = 4; hipLaunchKernelGGL((xt_gemm_kernel<MT, 4>), grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws); }
+    GATMI_LAUNCH_CHECK("xt_gemm");
+    const int Fp = gy * MT * 16;
+    hipLaunchKernelGGL(reduce_dw_kernel, dim3((F * hd + 255) / 256), dim3(256), 0, st, ws, (int)gx, Fp, nt_pad * 16, F, hd, dW);
+    GATMI_LAUNCH_CHECK("reduce_dw");
+    return GATMI_OK;
+}
+
+}  // namespace gatmi
+
+using namespace gatmi;
+
+extern "C" int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t ldx,
+                              const float *W, const float *a1, const float *a2,
+                              const float *b1, const float *b2, int32_t H, int32_t dp,
+                              float *Wh, float *f1, float *f2,
+                              const float *W_res, const float *b_res, float *res_out, void *stream) {
+    int G, LPH;
+    int rc = check_shape(H, dp, &G, &LPH);
+    if (rc) return rc;
+    GATMI_REQUIRE(n >= 0 && f_in > 0 && ldx >= f_in, GATMI_EINVAL, "proj_fwd: bad dims n=%lld f_in=%d ldx=%lld", (long long)n, f_in, (long long)ldx);
+    if (n == 0) return GATMI_OK;
+    GATMI_REQUIRE(X && W && Wh, GATMI_EINVAL, "proj_fwd: null pointer");
+    const bool logits = f1 || f2;
+    GATMI_REQUIRE(!logits || (f1 && f2 && a1 && a2 && b1 && b2), GATMI_EINVAL, "proj_fwd: f1, f2, a1, a2, b1, b2 go together");
+    GATMI_REQUIRE((W_res == nullptr) == (res_out == nullptr), GATMI_EINVAL, "proj_fwd: W_res and res_out go together");
+    GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(a1); GATMI_REQUIRE_ALIGNED(a2); GATMI_REQUIRE_ALIGNED(res_out);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int hd = H * dp;
+    GemmArgs g{};
+    g.A = X; g.n = n; g.K = f_in; g.lda = ldx;
+    g.B = W; g.sbk = hd; g.sbc = 1; g.Nc = hd;
+    g.C = Wh; g.ldc = hd; g.accumulate = 0; g.cbias = nullptr;
+    const bool fused = logits && hd <= kTileCols;
+    if (fused) { g.a1 = a1; g.a2 = a2; g.b1 = b1; g.b2 = b2; g.f1 = f1; g.f2 = f2; g.H = H; g.LPH = LPH; }
+    rc = launch_tall_gemm(g, st, "proj_fwd");
+    if (rc) return rc;
+    if (logits && !fused) {
+        if (G == 32) rc = launch_logit_halves<32>(Wh, n, H, LPH, a1, a2, b1, b2, f1, f2, st);
+        else rc = launch_logit_halves<64>(Wh, n, H, LPH, a1, a2, b1, b2, f1, f2, st);
+        if (rc) return rc;
+    }
+    if (W_res) {
+        GemmArgs r{};
+        r.A = X; r.n = n; r.K = f_in; r.lda = ldx;
+        r.B = W_res; r.sbk = hd; r.sbc = 1; r.Nc = hd;
+        r.C = res_out; r.ldc = hd; r.accumulate = 0; r.cbias = b_res;
+        rc = launch_tall_gemm(r, st, "proj_fwd residual");
+        if (rc) return rc;
+    }
+    return GATMI_OK;
+}
+
+static inline int dw_mt(int f_in) { return f_in <= 16 ? 1 : (f_in <= 32 ? 2 : (f_in <= 64 ? 4 : 7)); }
+
+extern "C" size_t gatmi_proj_bwd_ws_floats(int32_t f_in, int32_t H, int32_t dp) {
+    const int hd = H * dp;
+    const int mt = dw_mt(f_in);
+    const size_t fp = (size_t)((f_in + mt * 16 - 1) / (mt * 16)) * mt * 16;
+    const size_t dw = (size_t)kRedBlocks * fp * 64;
+    const size_t da = (size_t)kRedBlocks * (size_t)(2 * hd + 2 * H);
+    return std::max(dw, da);
+}
+
+extern "C" int gatmi_proj_bwd_params(const float *X, int64_t n, int32_t f_in, int64_t ldx,
+                                     const float *dWh, const float *Wh, const float *df1, const float *df2,
+                                     int32_t H, int32_t dp,
+                                     float *dW, float *da1, float *da2, float *db1, float *db2,
+                                     float *ws, void *stream) {
+    int G, LPH;
+    int rc = check_shape(H, dp, &G, &LPH);
+    if (rc) return rc;
+    GATMI_REQUIRE(n >= 0 && f_in > 0 && ldx >= f_in, GATMI_EINVAL, "proj_bwd_params: bad dims");
+    GATMI_REQUIRE(X && dWh && dW && ws, GATMI_EINVAL, "proj_bwd_params: null pointer");
+    GATMI_REQUIRE(!Wh || (df1 && df2 && da1 && da2 && db1 && db2), GATMI_EINVAL, "proj_bwd_params: Wh needs df1, df2, da1, da2, db1, db2");
+    GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(ws);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int hd = H * dp;
+    if (Wh) {
+#define X_(gg) if (G == gg) rc = launch_attn_param_grad<gg>(Wh, df1, df2, n, H, LPH, ws, da1, da2, db1, db2, st);
+        X_(1) X_(2) X_(4) X_(8) X_(16) X_(32) X_(64)
+#undef X_
+        if (rc) return rc;
+    }
+    // dW in column slabs of 64 (one slab for hd <= 64)
+    for (int c0 = 0; c0 < hd; c0 += 64) {
+        const int w = std::min(64, hd - c0);
+        GATMI_REQUIRE(c0 == 0, GATMI_EUNSUPPORTED, "proj_bwd_params: hd=%d > 64 not built yet (slab of %d)", hd, w);
+        switch (dw_mt(f_in)) {
+            case 1: rc = launch_xt_gemm<1>(X, n, f_in, ldx, dWh, hd, ws, dW, st); break;
+            case 2: rc = launch_xt_gemm<2>(X, n, f_in, ldx, dWh, hd, ws, dW, st); break;
+            case 4: rc = launch_xt_gemm<4>(X, n, f_in, ldx, dWh, hd, ws, dW, st); break;
+            default: rc = launch_xt_gemm<7>(X, n, f_in, ldx, dWh, hd, ws, dW, st); break;
+        }
+        if (rc) return rc;
+    }
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_proj_bwd_input(const float *dWh, int64_t n, int32_t f_in, const float *W,
+                                    int32_t H, int32_t dp, float *dX, int64_t lddx, int accumulate,
+                                    void *stream) {
+    int G, LPH;
+    int rc = check_shape(H, dp, &G, &LPH);
+    if (rc) return rc;
+    GATMI_REQUIRE(n >= 0 && f_in > 0 && lddx >= f_in, GATMI_EINVAL, "proj_bwd_input: bad dims");
+    if (n == 0) return GATMI_OK;
+    GATMI_REQUIRE(dWh && W && dX, GATMI_EINVAL, "proj_bwd_input: null pointer");
+    GATMI_REQUIRE_ALIGNED(dWh);
+    const int hd = H * dp;
+    GemmArgs g{};
+    g.A = dWh; g.n = n; g.K = hd; g.lda = hd;
+    g.B = W; g.sbk = 1; g.sbc = hd; g.Nc = f_in;   // B[k=c_hd][c=f] = W[f][c_hd]
+    g.C = dX; g.ldc = lddx; g.accumulate = accumulate; g.cbias = nullptr;
+    return launch_tall_gemm(g, reinterpret_cast<hipStream_t>(stream), "proj_bwd_input");
+}

@@ -1,0 +1,136 @@
+"""Graph handle for the sparse attention kernels: destination-major CSR, its CSC transpose and the
+length-sorted work-item lists both row kernels walk.
+
+Orientation follows the reference: entry (i, j) lets destination i attend to source j, exactly
+like bias_mat[i][j] == 0 in utils/layers.py:16-17.  The reference's sparse triple
+(utils/process.py:186-188) stores indices[:, 0] = SparseTensor row = i and indices[:, 1] = j.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+DEFAULT_CHUNK = 256
+
+
+def _work_items(ptr_host, chunk):
+    """gatmi_work_items on a host int64 pointer array -> (items [n_items,4] int32, split [n_split,4] int32, n_slots)."""
+    n = len(ptr_host) - 1
+    ptr_host = np.ascontiguousarray(ptr_host, dtype=np.int64)
+    n_items, n_split, n_slots = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    _lib.call("gatmi_work_items_count", n, _lib.ptr(ptr_host), chunk,
+              ctypes.byref(n_items), ctypes.byref(n_split), ctypes.byref(n_slots))
+    items = np.empty((n_items.value, 4), dtype=np.int32)
+    split = np.empty((n_split.value, 4), dtype=np.int32)
+    _lib.call("gatmi_work_items", n, _lib.ptr(ptr_host), chunk, _lib.ptr(items), _lib.ptr(split))
+    return items, split, n_slots.value
+
+
+def csr_from_coo_host(n, dst, src, add_self_loops=False, dedup=True):
+    """Host COO -> CSR through the C ABI.  Returns (rowptr int64 [n+1], col int32 [E], perm int64 [E])."""
+    dst = np.ascontiguousarray(dst, dtype=np.int32)
+    src = np.ascontiguousarray(src, dtype=np.int32)
+    nnz = len(dst)
+    cap = nnz + (n if add_self_loops else 0)
+    rowptr = np.empty(n + 1, dtype=np.int64)
+    col = np.empty(max(cap, 1), dtype=np.int32)
+    perm = np.empty(max(cap, 1), dtype=np.int64)
+    out = ctypes.c_int64()
+    _lib.call("gatmi_csr_from_coo", n, nnz, _lib.ptr(dst), _lib.ptr(src), int(add_self_loops), int(dedup), cap,
+              _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(perm), ctypes.byref(out))
+    return rowptr, col[:out.value].copy(), perm[:out.value].copy()
+
+
+def csc_from_csr_host(n_rows, n_cols, rowptr, col):
+    """Host CSR -> CSC through the C ABI.  Returns (colptr int64, rowidx int32, perm int32)."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    nnz = int(rowptr[-1])
+    colptr = np.empty(n_cols + 1, dtype=np.int64)
+    rowidx = np.empty(max(nnz, 1), dtype=np.int32)
+    perm = np.empty(max(nnz, 1), dtype=np.int32)
+    _lib.call("gatmi_csc_from_csr", n_rows, n_cols, _lib.ptr(rowptr), _lib.ptr(col),
+              _lib.ptr(colptr), _lib.ptr(rowidx), _lib.ptr(perm))
+    return colptr, rowidx[:nnz].copy(), perm[:nnz].copy()
+
+
+class CSRGraph:
+    """Device-resident adjacency of one (shard of a) graph.
+
+    n_dst rows (destinations) x n_src columns (sources).  On a single GPU n_dst == n_src; under
+    row partitioning n_src = owned + halo rows.
+    """
+
+    def __init__(self, n_dst, n_src, rowptr, col, colptr, rowidx, perm, device, chunk=DEFAULT_CHUNK):
+        self.n_dst, self.n_src = int(n_dst), int(n_src)
+        self.chunk = int(chunk)
+        self.device = torch.device(device)
+        self.rowptr_host = np.ascontiguousarray(rowptr, dtype=np.int64)
+        self.colptr_host = np.ascontiguousarray(colptr, dtype=np.int64)
+        self.nnz = int(self.rowptr_host[-1])
+        to = lambda a, dt: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(self.device, dt).contiguous()
+        self.col = to(col, torch.int32)
+        self.rowidx = to(rowidx, torch.int32)
+        self.perm = to(perm, torch.int32)
+        it, sp, self.n_slots_csr = _work_items(self.rowptr_host, self.chunk)
+        self.items_csr, self.split_csr = to(it, torch.int32), to(sp, torch.int32)
+        it, sp, self.n_slots_csc = _work_items(self.colptr_host, self.chunk)
+        self.items_csc, self.split_csc = to(it, torch.int32), to(sp, torch.int32)
+
+    # ---- constructors -------------------------------------------------------------------------
+    @classmethod
+    def from_coo(cls, dst, src, n, device, add_self_loops=False, dedup=True, chunk=DEFAULT_CHUNK):
+        """Host path: integer work done by the C++ builder of libgatmi (bit-exact, deterministic)."""
+        rowptr, col, _ = csr_from_coo_host(n, dst, src, add_self_loops, dedup)
+        colptr, rowidx, perm = csc_from_csr_host(n, n, rowptr, col)
+        return cls(n, n, rowptr, col, colptr, rowidx, perm, device, chunk)
+
+    @classmethod
+    def from_reference_triple(cls, adj_mat, device, chunk=DEFAULT_CHUNK):
+        """adj_mat = (indices [E,2], values [E], shape) as returned by preprocess_adj_bias
+        (utils/process.py:188) and fed to tf.sparse_placeholder (execute_cora_sparse.py:71,115)."""
+        indices, _values, shape = adj_mat
+        indices = np.asarray(indices)
+        assert shape[0] == shape[1], "adjacency must be square"
+        return cls.from_coo(indices[:, 0], indices[:, 1], int(shape[0]), device, False, True, chunk)
+
+    @classmethod
+    def from_csr(cls, rowptr, col, n_src, device, chunk=DEFAULT_CHUNK):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        n_dst = len(rowptr) - 1
+        colptr, rowidx, perm = csc_from_csr_host(n_dst, n_src, rowptr, col)
+        return cls(n_dst, n_src, rowptr, col, colptr, rowidx, perm, device, chunk)
+
+    @classmethod
+    def from_device_coo(cls, dst, src, n_dst, n_src, chunk=DEFAULT_CHUNK):
+        """Large graphs already on the GPU: dst/src int64 device tensors with DISTINCT (dst, src)
+        pairs.  Sorting runs on the device; only the two pointer arrays visit the host (for the
+        work-item builder).  Produces the same arrays as the host path."""
+        dev = dst.device
+        key = dst * n_src + src
+        key, _ = torch.sort(key)
+        d = torch.div(key, n_src, rounding_mode="floor")
+        col = (key - d * n_src).to(torch.int32)
+        rowptr = torch.zeros(n_dst + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.bincount(d, minlength=n_dst), 0)
+        # CSC: stable sort of the CSR entries by source keeps destinations ascending inside a column
+        _, order = torch.sort(col.to(torch.int64), stable=True)
+        rowidx = d[order].to(torch.int32)
+        perm = order.to(torch.int32)
+        colptr = torch.zeros(n_src + 1, dtype=torch.int64, device=dev)
+        colptr[1:] = torch.cumsum(torch.bincount(col.to(torch.int64), minlength=n_src), 0)
+        del key, d, order
+        return cls(n_dst, n_src, rowptr.cpu().numpy(), col, colptr.cpu().numpy(), rowidx, perm, dev, chunk)
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def in_degrees(self):
+        return np.diff(self.rowptr_host)
+
+    def out_degrees(self):
+        return np.diff(self.colptr_host)
+
+    def __repr__(self):
+        return "CSRGraph(n_dst=%d, n_src=%d, nnz=%d, chunk=%d, split rows csr/csc=%d/%d)" % (
+            self.n_dst, self.n_src, self.nnz, self.chunk, len(self.split_csr), len(self.split_csc))

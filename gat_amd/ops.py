@@ -1,0 +1,274 @@
+"""Autograd operators over the C ABI of libgatmi: one fused graph-attention layer (all heads)
+for CSR graphs and one for batched dense graphs.  PyTorch supplies device memory, streams and
+the autograd tape; every floating-point operation of the layer runs in the HIP kernels.
+
+Math and reference lines: utils/layers.py:6-34 (one head), models/sp_gat.py:12-17,27-32 (heads
+concatenated or averaged).
+"""
+import torch
+
+from . import _lib
+from ._lib import ptr
+
+LEAKY_SLOPE = 0.2  # tf.nn.leaky_relu default, utils/layers.py:17
+
+_ACT = {"elu": _lib.ACT_ELU, "identity": _lib.ACT_IDENTITY, None: _lib.ACT_IDENTITY}
+_RED = {"concat": _lib.REDUCE_CONCAT, "mean": _lib.REDUCE_MEAN}
+
+
+def padded_width(d):
+    """Per-head width used by the kernels: next power of two >= max(d, 4)."""
+    p = 4
+    while p < d:
+        p *= 2
+    return p
+
+
+def supported_shape(h, d):
+    dp = padded_width(d)
+    return h > 0 and (h & (h - 1)) == 0 and h * dp <= 256
+
+
+def _pad_last(t, d, dp):
+    if d == dp:
+        return t.contiguous()
+    return torch.nn.functional.pad(t, (0, dp - d)).contiguous()
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("gat_amd: the graph-attention kernels run on the GPU only; got a %s tensor "
+                               "(there is no CPU fallback)" % t.device)
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise TypeError("gat_amd: fp32 tensors expected, got %s" % t.dtype)
+    return t
+
+
+class _Cfg:
+    __slots__ = ("H", "D", "dp", "activation", "reduce", "slope", "coef_keep", "feat_keep", "seed")
+
+
+def _new(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _project(x2d, W, a1, a2, b1, b2, cfg, W_res=None, b_res=None):
+    """K1: Wh = X.W (+ f1, f2) on [n, F] rows.  Returns padded parameter views and outputs."""
+    n, F = x2d.shape
+    H, D, dp = cfg.H, cfg.D, cfg.dp
+    hd = H * dp
+    Wp = _pad_last(W.reshape(F, H, D), D, dp).reshape(F, hd)
+    a1p = _pad_last(a1.reshape(H, D), D, dp).reshape(hd)
+    a2p = _pad_last(a2.reshape(H, D), D, dp).reshape(hd)
+    b1c, b2c = b1.reshape(H).contiguous(), b2.reshape(H).contiguous()
+    Wh = _new((n, hd), x2d)
+    f1 = _new((n, H), x2d)
+    f2 = _new((n, H), x2d)
+    Wrp = brp = res = None
+    if W_res is not None:
+        Wrp = _pad_last(W_res.reshape(F, H, D), D, dp).reshape(F, hd)
+        brp = _pad_last(b_res.reshape(H, D), D, dp).reshape(hd)
+        res = _new((n, hd), x2d)
+    _lib.call("gatmi_proj_fwd", ptr(x2d), n, F, x2d.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1c), ptr(b2c),
+              H, dp, ptr(Wh), ptr(f1), ptr(f2), ptr(Wrp), ptr(brp), ptr(res), _lib.current_stream())
+    return Wp, a1p, a2p, Wrp, Wh, f1, f2, res
+
+
+def _project_backward(x2d, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, need_dx):
+    """Backward of _project: dW, da1, da2, db1, db2 (+ dW_res, db_res, dX)."""
+    n, F = x2d.shape
+    H, D, dp = cfg.H, cfg.D, cfg.dp
+    hd = H * dp
+    st = _lib.current_stream()
+    ws = _new((_lib.lib.gatmi_proj_bwd_ws_floats(F, H, dp),), x2d)
+    dW = _new((F, hd), x2d)
+    da1, da2 = _new((hd,), x2d), _new((hd,), x2d)
+    db1, db2 = _new((H,), x2d), _new((H,), x2d)
+    _lib.call("gatmi_proj_bwd_params", ptr(x2d), n, F, x2d.stride(0), ptr(dWh), ptr(Wh), ptr(df1), ptr(df2), H, dp,
+              ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(ws), st)
+    dWr = None
+    if Wrp is not None:
+        dWr = _new((F, hd), x2d)
+        _lib.call("gatmi_proj_bwd_params", ptr(x2d), n, F, x2d.stride(0), ptr(g), None, None, None, H, dp,
+                  ptr(dWr), None, None, None, None, ptr(ws), st)
+    dx = None
+    if need_dx:
+        dx = _new((n, F), x2d)
+        _lib.call("gatmi_proj_bwd_input", ptr(dWh), n, F, ptr(Wp), H, dp, ptr(dx), F, 0, st)
+        if Wrp is not None:
+            _lib.call("gatmi_proj_bwd_input", ptr(g), n, F, ptr(Wrp), H, dp, ptr(dx), F, 1, st)
+
+    def unpad(t, lead):
+        return t.reshape(*lead, H, dp)[..., :D]
+    return (dx, unpad(dW, (F,)), unpad(da1, ()), unpad(da2, ()), db1, db2,
+            None if dWr is None else unpad(dWr, (F,)))
+
+
+class SparseGATLayerFn(torch.autograd.Function):
+    """out = act( softmax-attention aggregate over the CSR graph + bias (+ residual) ), all heads."""
+
+    @staticmethod
+    def forward(ctx, x, W, a1, a2, b1, b2, bias, W_res, b_res, graph, cfg):
+        _require_cuda(x, W)
+        x = _f32(x).contiguous()
+        n, F = x.shape
+        if n != graph.n_dst or graph.n_src != graph.n_dst:
+            raise ValueError("x has %d rows but the graph is %d x %d" % (n, graph.n_dst, graph.n_src))
+        H, D, dp = cfg.H, cfg.D, cfg.dp
+        hd = H * dp
+        st = _lib.current_stream()
+        Wp, a1p, a2p, Wrp, Wh, f1, f2, res = _project(x, W, a1, a2, b1, b2, cfg, W_res, b_res)
+        biasp = None if bias is None else _pad_last(bias.reshape(H, D), D, dp).reshape(hd)
+        need_grad = any(ctx.needs_input_grad)
+        out_w = dp if cfg.reduce == "mean" else hd
+        out = _new((n, out_w), x)
+        agg = pos = lse = q = None
+        if need_grad:
+            agg, pos = _new((n, hd), x), _new((n, hd), x)
+            lse, q = _new((n, H), x), _new((n, H), x)
+        ws = None
+        if len(graph.split_csr):
+            ws = _new((_lib.lib.gatmi_gat_fwd_ws_floats(graph.n_slots_csr, H, dp),), x)
+        _lib.call("gatmi_gat_fwd", n, H, dp, ptr(graph.items_csr), len(graph.items_csr),
+                  ptr(graph.split_csr) if len(graph.split_csr) else None, len(graph.split_csr),
+                  ptr(graph.col), ptr(Wh), ptr(f1), ptr(f2), ptr(biasp), ptr(res),
+                  _ACT[cfg.activation], _RED[cfg.reduce], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
+                  ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
+        if need_grad:
+            ctx.graph, ctx.cfg = graph, cfg
+            ctx.has_bias, ctx.has_res = bias is not None, W_res is not None
+            ctx.save_for_backward(x, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q)
+        if cfg.reduce == "mean":
+            return out[:, :D] if D != dp else out
+        return out.reshape(n, H, dp)[:, :, :D].reshape(n, H * D) if D != dp else out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q = ctx.saved_tensors
+        graph, cfg = ctx.graph, ctx.cfg
+        H, D, dp = cfg.H, cfg.D, cfg.dp
+        hd = H * dp
+        n = x.shape[0]
+        st = _lib.current_stream()
+        if cfg.reduce == "mean":
+            dout = _pad_last(dout, D, dp)
+        else:
+            dout = _pad_last(dout.reshape(n, H, D), D, dp).reshape(n, hd)
+        g = _new((n, hd), x)
+        stats = _new((n, 3 * H), x)
+        df1 = _new((n, H), x)
+        dbias = _new((hd,), x)
+        ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x)
+        _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out), ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse),
+                  _ACT[cfg.activation], _RED[cfg.reduce], cfg.slope, ptr(g), ptr(stats), ptr(df1), ptr(dbias), ptr(ws), st)
+        dWh = _new((n, hd), x)
+        df2 = _new((n, H), x)
+        ws2 = None
+        if len(graph.split_csc):
+            ws2 = _new((_lib.lib.gatmi_gat_bwd_ws_floats(graph.n_slots_csc, H, dp),), x)
+        _lib.call("gatmi_gat_bwd_csc", n, H, dp, ptr(graph.items_csc), len(graph.items_csc),
+                  ptr(graph.split_csc) if len(graph.split_csc) else None, len(graph.split_csc),
+                  ptr(graph.rowidx), ptr(graph.perm), ptr(g), ptr(stats), ptr(Wh), ptr(f2), ptr(df1), ptr(a1p), ptr(a2p),
+                  cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dWh), ptr(df2), ptr(ws2), st)
+        dx, dW, da1, da2, db1, db2, dWr = _project_backward(x, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
+        db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None
+        dbr = dbias.reshape(H, dp)[:, :D] if ctx.has_res else None
+        return dx, dW, da1, da2, db1, db2, db, dWr, dbr, None, None
+
+
+class DenseGATLayerFn(torch.autograd.Function):
+    """Same layer on [B, N, F] inputs with an additive [B, N, N] mask (utils/layers.py:6-34)."""
+
+    @staticmethod
+    def forward(ctx, x, W, a1, a2, b1, b2, bias, W_res, b_res, bias_mat, cfg):
+        _require_cuda(x, W, bias_mat)
+        if cfg.reduce != "concat":
+            raise ValueError("dense layer: heads are concatenated by the kernel; average outside")
+        if cfg.coef_keep < 1.0 or cfg.feat_keep < 1.0:
+            raise NotImplementedError("dense layer: in-kernel dropout is only built for the CSR path")
+        x = _f32(x).contiguous()
+        B, N, F = x.shape
+        bias_mat = _f32(bias_mat).contiguous()
+        if tuple(bias_mat.shape) != (B, N, N):
+            raise ValueError("bias_mat must be [B,N,N] = [%d,%d,%d], got %s" % (B, N, N, tuple(bias_mat.shape)))
+        H, D, dp = cfg.H, cfg.D, cfg.dp
+        hd = H * dp
+        st = _lib.current_stream()
+        x2 = x.reshape(B * N, F)
+        Wp, a1p, a2p, Wrp, Wh, f1, f2, res = _project(x2, W, a1, a2, b1, b2, cfg, W_res, b_res)
+        biasp = None if bias is None else _pad_last(bias.reshape(H, D), D, dp).reshape(hd)
+        need_grad = any(ctx.needs_input_grad)
+        out = _new((B * N, hd), x)
+        agg = pos = lse = q = None
+        if need_grad:
+            agg, pos = _new((B * N, hd), x), _new((B * N, hd), x)
+            lse, q = _new((B * N, H), x), _new((B * N, H), x)
+        _lib.call("gatmi_dense_attn_fwd", B, N, H, dp, ptr(Wh), ptr(f1), ptr(f2), ptr(bias_mat), ptr(biasp), ptr(res),
+                  _ACT[cfg.activation], cfg.slope, ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), st)
+        if need_grad:
+            ctx.cfg, ctx.dims = cfg, (B, N)
+            ctx.has_bias, ctx.has_res = bias is not None, W_res is not None
+            ctx.save_for_backward(x2, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q, bias_mat)
+        o = out.reshape(B, N, H, dp)
+        return (o[..., :D] if D != dp else o).reshape(B, N, H * D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q, bias_mat = ctx.saved_tensors
+        cfg = ctx.cfg
+        B, N = ctx.dims
+        H, D, dp = cfg.H, cfg.D, cfg.dp
+        hd = H * dp
+        n = B * N
+        st = _lib.current_stream()
+        dout = _pad_last(dout.reshape(n, H, D), D, dp).reshape(n, hd)
+        g = _new((n, hd), x2)
+        stats = _new((n, 3 * H), x2)
+        df1 = _new((n, H), x2)
+        dbias = _new((hd,), x2)
+        ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x2)
+        _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out), ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse),
+                  _ACT[cfg.activation], _lib.REDUCE_CONCAT, cfg.slope, ptr(g), ptr(stats), ptr(df1), ptr(dbias), ptr(ws), st)
+        dWh = _new((n, hd), x2)
+        df2 = _new((n, H), x2)
+        _lib.call("gatmi_dense_attn_bwd", B, N, H, dp, ptr(g), ptr(stats), ptr(Wh), ptr(f2), ptr(bias_mat),
+                  ptr(df1), ptr(a1p), ptr(a2p), cfg.slope, ptr(dWh), ptr(df2), st)
+        dx, dW, da1, da2, db1, db2, dWr = _project_backward(x2, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
+        if dx is not None:
+            dx = dx.reshape(B, N, -1)
+        db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None
+        dbr = dbias.reshape(H, dp)[:, :D] if ctx.has_res else None
+        return dx, dW, da1, da2, db1, db2, db, dWr, dbr, None, None
+
+
+def make_cfg(H, D, activation="elu", reduce="concat", coef_drop=0.0, in_drop=0.0, training=False, seed=None,
+             slope=LEAKY_SLOPE):
+    """Static description of one layer call.  coef_drop / in_drop are the reference's dropout
+    rates (utils/layers.py:20,22); they act only when training is true, and rate 0 is an exact
+    identity (no mask is drawn)."""
+    if activation not in _ACT:
+        raise ValueError("activation must be 'elu' or 'identity', got %r" % (activation,))
+    if not supported_shape(H, D):
+        raise ValueError("heads=%d width=%d: the fused kernels need a power-of-two head count and heads * "
+                         "padded width <= 256; call the layer per head instead" % (H, D))
+    c = _Cfg()
+    c.H, c.D, c.dp = int(H), int(D), padded_width(int(D))
+    c.activation, c.reduce, c.slope = activation, reduce, float(slope)
+    c.coef_keep = 1.0 - float(coef_drop) if training else 1.0
+    c.feat_keep = 1.0 - float(in_drop) if training else 1.0
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (c.coef_keep < 1.0 or c.feat_keep < 1.0) else 0
+    c.seed = int(seed)
+    return c
+
+
+def sparse_gat_layer(x, W, a1, a2, b1, b2, bias, graph, cfg, W_res=None, b_res=None):
+    return SparseGATLayerFn.apply(x, W, a1, a2, b1, b2, bias, W_res, b_res, graph, cfg)
+
+
+def dense_gat_layer(x, W, a1, a2, b1, b2, bias, bias_mat, cfg, W_res=None, b_res=None):
+    return DenseGATLayerFn.apply(x, W, a1, a2, b1, b2, bias, W_res, b_res, bias_mat, cfg)

@@ -1,0 +1,215 @@
+/*
+ * gatmi.h — C ABI of libgatmi.so: a graph-attention (GAT) layer for AMD MI355X (gfx950).
+ *
+ * The reference (zhangtianer521/GAT, TensorFlow 1.x, pure Python) has no FFI of its own; its
+ * boundary for this path is the Python functions
+ *     utils/layers.py:6      attn_head(seq, out_sz, bias_mat, activation, in_drop, coef_drop, residual)
+ *     models/sp_gat.py:13    layers.sp_attn_head(seq, out_sz, adj_mat, activation, nb_nodes, ...)
+ *     utils/process.py:14    adj_to_bias(adj, sizes, nhood)
+ *     utils/process.py:179   preprocess_adj_bias(adj)
+ * The entry points below are what a ctypes binding placed under those functions calls.  Each
+ * one names the reference lines whose work it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++ types, no exceptions cross the boundary;
+ *   - every function returns GATMI_OK (0) or a negative GATMI_E* code; the message for the last
+ *     failure on the calling thread is returned by gatmi_last_error();
+ *   - the caller owns every buffer; the library allocates no device memory and keeps no pointer
+ *     after it returns; scratch is a caller-provided workspace sized by gatmi_*_ws_floats();
+ *   - device entry points ENQUEUE on `stream` (a hipStream_t passed as void*) and return without
+ *     synchronising; the current device must be the one that owns the buffers;
+ *   - feature matrices are row-major fp32 with `hd = H * dp` columns, where dp (the padded
+ *     per-head width) is a power of two >= 4 and hd / 4 is a power of two <= 64; padded columns
+ *     must be zero in W, a1, a2, bias;
+ *   - rowptr/colptr are int64, node ids / edge offsets inside work items are int32 (a single
+ *     GPU's shard must have fewer than 2^31 stored edges and nodes).
+ *
+ * Graph orientation: CSR row i = DESTINATION node i, col = SOURCE ids j, i.e. entry (i, j) of the
+ * reference's bias_mat / SparseTensor adjacency (utils/layers.py:16: logits[i][j] = f_1[i] + f_2[j]).
+ */
+#ifndef GATMI_H
+#define GATMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GATMI_OK            0
+#define GATMI_EINVAL       -1   /* null pointer, negative size, inconsistent dims            */
+#define GATMI_EALIGN       -2   /* device pointer not 16-byte aligned                        */
+#define GATMI_EUNSUPPORTED -3   /* (H, dp) combination not built, unknown activation, ...    */
+#define GATMI_EHIP         -4   /* HIP launch / runtime error (text in gatmi_last_error)     */
+#define GATMI_ERANGE       -5   /* index out of range in host input, or 32-bit overflow      */
+
+#define GATMI_ACT_IDENTITY 0    /* `lambda x: x`, models/sp_gat.py:30 */
+#define GATMI_ACT_ELU      1    /* tf.nn.elu,     models/sp_gat.py:9  */
+
+#define GATMI_REDUCE_CONCAT 0   /* tf.concat(attns, -1), models/sp_gat.py:17 */
+#define GATMI_REDUCE_MEAN   1   /* tf.add_n(out) / n,    models/sp_gat.py:32 (identity activation only) */
+
+int gatmi_version(void);
+const char *gatmi_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Host integer API (pure C++ inside, no GPU needed).  Replaces the adjacency handling of
+ * utils/process.py:179-188 downstream of its (indices, values, shape) triple.
+ * ---------------------------------------------------------------------------------------- */
+
+/* COO -> CSR, destination-major, each row sorted by source id.
+ *   dst[k], src[k] : entry k (for the reference's triple: dst = indices[:,0], src = indices[:,1])
+ *   add_self_loops : insert (i,i) for every i that lacks it (process.py:181 already does)
+ *   dedup          : merge repeated (dst,src) pairs into one entry (process.py:182 binarises)
+ * Outputs: rowptr_out[n+1]; col_out[cap]; perm_out[cap] (input position of each output entry,
+ * -1 for an inserted self-loop; may be NULL); *nnz_out = entries written.  cap must be
+ * >= nnz + (add_self_loops ? n : 0). */
+int gatmi_csr_from_coo(int64_t n, int64_t nnz, const int32_t *dst, const int32_t *src,
+                       int add_self_loops, int dedup, int64_t cap,
+                       int64_t *rowptr_out, int32_t *col_out, int64_t *perm_out, int64_t *nnz_out);
+
+/* CSR -> CSC of the same matrix: for every source j the destinations i that read it, sorted by
+ * i, and perm_out[k] = CSR position of CSC entry k (used to key per-edge dropout). */
+int gatmi_csc_from_csr(int64_t n_rows, int64_t n_cols, const int64_t *rowptr, const int32_t *col,
+                       int64_t *colptr_out, int32_t *rowidx_out, int32_t *perm_out);
+
+/* Work items for the row kernels: rows are cut into pieces of at most `chunk` entries and the
+ * pieces are ordered longest first (stable by row id), so that a wave's row groups carry similar
+ * lengths and long rows start early.  A row of <= chunk entries is one item with slot = -1; a
+ * longer row becomes ceil(len/chunk) items that own consecutive partial-result slots and one
+ * record in the split list.  item = {row, first_entry, n_entries, slot} (4 x int32);
+ * split record = {row, first_slot, n_slots, 0}.
+ * gatmi_work_items_count gives the array sizes; gatmi_work_items fills them. */
+int gatmi_work_items_count(int64_t n, const int64_t *ptr, int32_t chunk,
+                           int64_t *n_items_out, int64_t *n_split_out, int64_t *n_slots_out);
+int gatmi_work_items(int64_t n, const int64_t *ptr, int32_t chunk,
+                     int32_t *items_out, int32_t *split_out);
+
+/* Contiguous 1-D row partition into nparts blocks: part_out[nparts+1], part p owns rows
+ * [part_out[p], part_out[p+1]).  balance = 0: equal row counts; 1: equal stored-entry counts. */
+int gatmi_partition_rows(int64_t n, int32_t nparts, const int64_t *rowptr, int32_t balance,
+                         int64_t *part_out);
+
+/* Halo plan of one partition: its CSR rows [part[rank], part[rank+1]) with GLOBAL source ids in
+ * col[0..nnz) are rewritten to local ids: owned j -> j - part[rank]; remote j -> n_own + (rank
+ * of j in the sorted list of distinct remote ids).  halo_ids_out (capacity nnz) receives that
+ * sorted list (ascending global id, hence grouped by owner), halo_counts_out[nparts] the number
+ * of halo rows owned by each peer, *n_halo_out the list length. */
+int gatmi_halo_plan(int32_t nparts, int32_t rank, const int64_t *part, int64_t nnz,
+                    const int64_t *col_global, int32_t *col_local_out,
+                    int64_t *halo_ids_out, int64_t *halo_counts_out, int64_t *n_halo_out);
+
+/* ------------------------------------------------------------------------------------------
+ * Device API
+ * ---------------------------------------------------------------------------------------- */
+
+/* Feature projection with the logit halves fused: replaces utils/layers.py:11 (seq_fts = X.W,
+ * no bias), :14 (f_1 = seq_fts.a1 + b1) and :15 (f_2 = seq_fts.a2 + b2) for all H heads at once.
+ *   X [n, f_in] (row stride ldx floats), W [f_in, hd], a1,a2 [hd], b1,b2 [H]
+ *   Wh [n, hd], f1,f2 [n, H].  W_res/b_res/res_out: optional second projection of the same X
+ *   (residual branch, utils/layers.py:30), NULL to skip. */
+int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t ldx,
+                   const float *W, const float *a1, const float *a2,
+                   const float *b1, const float *b2, int32_t H, int32_t dp,
+                   float *Wh, float *f1, float *f2,
+                   const float *W_res, const float *b_res, float *res_out, void *stream);
+
+/* Parameter gradients of the projection: dW = X^T . dWh [f_in, hd]; and, when Wh != NULL,
+ * da1 = sum_i df1[i,h] * Wh[i,h,:], da2 likewise with df2, db1 = sum_i df1, db2 = sum_i df2
+ * (the backward of layers.py:11,14,15).  ws: gatmi_proj_bwd_ws_floats(f_in, H, dp) floats. */
+size_t gatmi_proj_bwd_ws_floats(int32_t f_in, int32_t H, int32_t dp);
+int gatmi_proj_bwd_params(const float *X, int64_t n, int32_t f_in, int64_t ldx,
+                          const float *dWh, const float *Wh, const float *df1, const float *df2,
+                          int32_t H, int32_t dp,
+                          float *dW, float *da1, float *da2, float *db1, float *db2,
+                          float *ws, void *stream);
+
+/* Input gradient of the projection: dX [n, f_in] (row stride lddx) = dWh . W^T
+ * (+= when accumulate != 0). */
+int gatmi_proj_bwd_input(const float *dWh, int64_t n, int32_t f_in, const float *W,
+                         int32_t H, int32_t dp, float *dX, int64_t lddx, int accumulate,
+                         void *stream);
+
+/* Fused CSR edge-softmax + neighbour aggregation, forward.  Replaces utils/layers.py:16-17
+ * (logits, LeakyReLU, additive mask, softmax), :20 (coefficient dropout), :22 (feature dropout),
+ * :24 (coefs . seq_fts), :25 (bias_add), :30 (residual add), :34 (activation) and the head
+ * concat / mean of models/sp_gat.py:17,32 — for all H heads.
+ *   items/n_items, split/n_split : gatmi_work_items of the CSR rowptr; col: CSR source ids
+ *   feat [n_src, hd] gathered rows (Wh); f1 [n_dst, H]; f2 [n_src, H]
+ *   bias [hd] or NULL; resid [n_dst, hd] or NULL (added before the activation)
+ *   out [n_dst, hd] (concat) or [n_dst, dp] (mean)
+ *   agg, pos [n_dst, hd], lse, q [n_dst, H]: saved for the backward pass, all NULL for inference
+ *       agg = sum_j alpha_ij feat_j (before bias), pos = same sum over entries with positive
+ *       pre-LeakyReLU logit, q = sum of alpha over those entries, lse = log sum exp of the row
+ *   ws: gatmi_gat_fwd_ws_floats(n_slots, H, dp) floats when n_split > 0
+ *   coef_keep / feat_keep in (0,1]: keep probabilities of layers.py:20 / :22 (1 = no dropout);
+ *   masks are a counter-based hash of (seed, CSR entry position, head) / (seed, src, column). */
+size_t gatmi_gat_fwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp);
+int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
+                  const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
+                  const int32_t *col, const float *feat, const float *f1, const float *f2,
+                  const float *bias, const float *resid, int32_t activation, int32_t reduce,
+                  float slope, float coef_keep, float feat_keep, uint64_t seed,
+                  float *out, float *agg, float *pos, float *lse, float *q,
+                  float *ws, void *stream);
+
+/* Backward, per-destination part (no gather).  From dOut and the saved forward tensors:
+ *   g [n_dst, hd]    = dOut * activation'(out)              (dOut / H per head for mean)
+ *   stats [n_dst, 3, H] = {f1, lse, c}, c = <g, agg> per head
+ *   df1 [n_dst, H]   = (1 - slope) * (<g, pos> - c * q)     = sum_j dlogit_ij  (gradient of f_1)
+ *   dbias [hd]       = sum_i g (NULL to skip);  dresid is g itself.
+ *   ws: gatmi_gat_bwd_node_ws_floats(H, dp). */
+size_t gatmi_gat_bwd_node_ws_floats(int32_t H, int32_t dp);
+int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
+                       const float *dout, const float *out, const float *agg, const float *pos,
+                       const float *q, const float *f1, const float *lse,
+                       int32_t activation, int32_t reduce, float slope,
+                       float *g, float *stats, float *df1, float *dbias, float *ws, void *stream);
+
+/* Backward, per-source part: transposed SpMM + SDDMM over the CSC structure.
+ *   items/split: gatmi_work_items of colptr; rowidx: CSC destination ids; perm: CSR position of
+ *   each CSC entry (only read when coef_keep < 1, may be NULL otherwise)
+ *   dfeat [n_src, hd] = sum_i alpha_ij g_i  (+ df1_j a1 + df2_j a2 when a1 != NULL: then dfeat
+ *       is the full gradient of Wh = seq_fts and df1 [n_src, H] must be given)
+ *   df2 [n_src, H]    = sum_i dlogit_ij */
+size_t gatmi_gat_bwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp);
+int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
+                      const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
+                      const int32_t *rowidx, const int32_t *perm,
+                      const float *g, const float *stats, const float *feat, const float *f2,
+                      const float *df1, const float *a1, const float *a2,
+                      float slope, float coef_keep, float feat_keep, uint64_t seed,
+                      float *dfeat, float *df2, float *ws, void *stream);
+
+/* Batched dense masked attention (small graphs).  Replaces utils/layers.py:16-25,34 on
+ * [B, N, *] tensors with the additive bias_mat [B, N, N] of utils/process.py:14-25 (any additive
+ * values, not only 0 / -1e9).
+ *   Wh [B,N,hd], f1,f2 [B,N,H], bias [hd] or NULL, resid [B,N,hd] or NULL; out [B,N,hd];
+ *   agg, pos [B,N,hd], lse, q [B,N,H]: saved for backward (meaning as in gatmi_gat_fwd), or all NULL. */
+int gatmi_dense_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t dp,
+                         const float *Wh, const float *f1, const float *f2, const float *bias_mat,
+                         const float *bias, const float *resid, int32_t activation, float slope,
+                         float *out, float *agg, float *pos, float *lse, float *q, void *stream);
+
+/* Backward of the above, per-source part.  g, stats and df1 come from gatmi_gat_bwd_node run on
+ * the B*N rows.  dWh [B,N,hd] = sum_i alpha_ij g_i (+ df1_j a1 + df2_j a2 when a1 != NULL),
+ * df2 [B,N,H] = sum_i dlogit_ij. */
+int gatmi_dense_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t dp,
+                         const float *g, const float *stats, const float *Wh, const float *f2,
+                         const float *bias_mat, const float *df1, const float *a1, const float *a2,
+                         float slope, float *dWh, float *df2, void *stream);
+
+/* Halo exchange helpers (row-partitioned multi-GPU).  pack: dst[k, :] = src[idx[k], :] for
+ * k < n_idx, rows of `width` floats (send buffer of Wh / f2 rows requested by a peer).
+ * unpack_add: dst[idx[k], :] += src[k, :] (gradient rows returned by a peer; idx may repeat
+ * across peers but not inside one call). */
+int gatmi_halo_pack(const float *src, const int64_t *idx, int64_t n_idx, int32_t width,
+                    float *dst, void *stream);
+int gatmi_halo_unpack_add(const float *src, const int64_t *idx, int64_t n_idx, int32_t width,
+                          float *dst, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GATMI_H */

@@ -1,0 +1,152 @@
+"""GPU parity of the fused CSR graph-attention layer (through the C ABI) against the oracle.
+
+Forward outputs are compared with the float64 numpy restatement of utils/layers.py:6-34 restricted
+to stored entries (oracle/ref_numpy.py); gradients with the float64 torch restatement
+(oracle/ref_torch.py).  Tolerance: 1e-5 relative plus 2e-6 of the tensor's scale (fp32 kernels,
+different summation order).  The oracle is "parity unpinned" against TensorFlow (not installed).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_numpy, ref_torch
+from tests.util import assert_close, layer_params, random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_layer(n, F, H, D, dst, src, activation, reduce, seed, res=False, chunk=256, need_dx=True):
+    from gat_amd import CSRGraph, ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    p = layer_params(F, H, D, seed + 1, res=res)
+    x = rng.normal(0, 1, (n, F))
+    graph = CSRGraph.from_coo(dst, src, n, dev, chunk=chunk)
+    tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+    xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=need_dx)
+    cfg = ops.make_cfg(H, D, activation=activation, reduce=reduce)
+    out = ops.sparse_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], graph, cfg,
+                               tp.get("W_res"), tp.get("b_res"))
+    rowptr, col = ref_numpy.coo_to_csr(np.stack([dst, src], 1), n)
+    return x, p, tp, xt, out, rowptr, col
+
+
+def _check_param_grads(tp, rp, keys, n):
+    """Parameter gradients.  db1 / db2 are sums of per-node logit gradients that cancel almost
+    completely, so their tolerance is relative to the sum of |terms| (the oracle is run with the
+    scalar bias broadcast to one leaf per node to expose the terms), not to the tiny result."""
+    for k in keys:
+        ref = rp[k].grad.numpy()
+        if k in ("b1", "b2"):
+            terms = ref                       # [n, H] per-node gradients
+            ref = terms.sum(0)
+            got = tp[k].grad.cpu().numpy().astype(np.float64)
+            tol = 1e-5 * np.abs(ref) + 1e-6 * np.abs(terms).sum(0)
+            assert (np.abs(got - ref) <= tol).all(), "d%s: got %s ref %s tol %s" % (k, got, ref, tol)
+        else:
+            assert_close(tp[k].grad.cpu().numpy(), ref, atol_scale=5e-6, what="d" + k)
+
+
+def _oracle_leaves(p, n):
+    rp = {}
+    for k, v in p.items():
+        if k in ("b1", "b2"):
+            v = np.broadcast_to(v, (n, v.shape[0])).copy()
+        rp[k] = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+    return rp
+
+
+CASES = [
+    # n, F, H, D, avg_deg, activation, reduce
+    (257, 20, 8, 8, 6.0, "elu", "concat"),
+    (300, 33, 1, 7, 4.0, "identity", "mean"),
+    (190, 16, 4, 8, 9.0, "identity", "concat"),
+    (128, 64, 1, 64, 5.0, "elu", "concat"),
+    (200, 12, 2, 16, 3.0, "elu", "concat"),
+    (150, 10, 8, 4, 5.0, "identity", "mean"),
+]
+
+
+@pytest.mark.parametrize("n,F,H,D,deg,activation,reduce", CASES)
+def test_forward_matches_float64_oracle(n, F, H, D, deg, activation, reduce):
+    dst, src = random_graph(n, deg, seed=n)
+    x, p, tp, xt, out, rowptr, col = _run_layer(n, F, H, D, dst, src, activation, reduce, seed=n + 7)
+    act = ref_numpy.elu if activation == "elu" else ref_numpy.identity
+    ref = ref_numpy.gat_layer_csr(x, p, rowptr, col, activation=act, reduce=reduce)
+    assert_close(out.detach().cpu().numpy(), ref, what="forward")
+
+
+@pytest.mark.parametrize("n,F,H,D,deg,activation,reduce", CASES)
+def test_gradients_match_float64_oracle(n, F, H, D, deg, activation, reduce):
+    dst, src = random_graph(n, deg, seed=n)
+    x, p, tp, xt, out, rowptr, col = _run_layer(n, F, H, D, dst, src, activation, reduce, seed=n + 7)
+    rng = np.random.default_rng(99)
+    dout = rng.normal(0, 1, tuple(out.shape))
+    out.backward(torch.tensor(dout, dtype=torch.float32, device=out.device))
+
+    rp = _oracle_leaves(p, n)
+    rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    rout = ref_torch.layer_csr(rx, rp, torch.tensor(rowptr), torch.tensor(col), activation, reduce)
+    rout.backward(torch.tensor(dout, dtype=torch.float64))
+    assert_close(out.detach().cpu().numpy(), rout.detach().numpy(), what="forward(torch oracle)")
+    assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what="dX")
+    _check_param_grads(tp, rp, ("W", "a1", "a2", "b1", "b2", "bias"), n)
+
+
+def test_hub_rows_are_split_and_merged():
+    """Rows and columns far longer than the chunk size go through the partial-result merge."""
+    n, F, H, D = 600, 24, 8, 8
+    dst, src = random_graph(n, 3.0, seed=5, hubs=3, hub_deg=500)
+    x, p, tp, xt, out, rowptr, col = _run_layer(n, F, H, D, dst, src, "elu", "concat", seed=11, chunk=32)
+    assert np.diff(rowptr).max() > 32 * 4
+    ref = ref_numpy.gat_layer_csr(x, p, rowptr, col, activation=ref_numpy.elu, reduce="concat")
+    assert_close(out.detach().cpu().numpy(), ref, what="forward with split rows")
+    rng = np.random.default_rng(3)
+    dout = rng.normal(0, 1, tuple(out.shape))
+    out.backward(torch.tensor(dout, dtype=torch.float32, device=out.device))
+    rp = _oracle_leaves(p, n)
+    rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    rout = ref_torch.layer_csr(rx, rp, torch.tensor(rowptr), torch.tensor(col), "elu", "concat")
+    rout.backward(torch.tensor(dout, dtype=torch.float64))
+    assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what="dX")
+    _check_param_grads(tp, rp, ("W", "a1", "a2", "b1", "b2", "bias"), n)
+
+
+def test_residual_projection():
+    n, F, H, D = 220, 18, 4, 8
+    dst, src = random_graph(n, 5.0, seed=21)
+    x, p, tp, xt, out, rowptr, col = _run_layer(n, F, H, D, dst, src, "elu", "concat", seed=31, res=True)
+    rp = _oracle_leaves(p, n)
+    rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    rout = ref_torch.layer_csr(rx, rp, torch.tensor(rowptr), torch.tensor(col), "elu", "concat", residual=True)
+    assert_close(out.detach().cpu().numpy(), rout.detach().numpy(), what="forward residual")
+    dout = np.random.default_rng(8).normal(0, 1, tuple(out.shape))
+    out.backward(torch.tensor(dout, dtype=torch.float32, device=out.device))
+    rout.backward(torch.tensor(dout, dtype=torch.float64))
+    assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what="dX")
+    _check_param_grads(tp, rp, ("W", "a1", "a2", "b1", "b2", "bias", "W_res", "b_res"), n)
+
+
+def test_known_answers():
+    """Analytic cases: zero attention vectors => uniform coefficients => neighbour mean;
+    a lone node with a self-loop => its own projected features."""
+    from gat_amd import CSRGraph, ops
+    dev = torch.device("cuda:0")
+    n, F, H, D = 40, 6, 2, 4
+    dst, src = random_graph(n, 3.0, seed=2)
+    rng = np.random.default_rng(0)
+    x = rng.normal(0, 1, (n, F)).astype(np.float32)
+    W = rng.normal(0, 1, (F, H, D)).astype(np.float32)
+    z = lambda *s: torch.zeros(*s, device=dev)
+    graph = CSRGraph.from_coo(dst, src, n, dev)
+    cfg = ops.make_cfg(H, D, activation="identity")
+    out = ops.sparse_gat_layer(torch.tensor(x, device=dev), torch.tensor(W, device=dev), z(H, D), z(H, D), z(H), z(H),
+                               z(H, D), graph, cfg).cpu().numpy()
+    wh = x.astype(np.float64) @ W.reshape(F, H * D).astype(np.float64)
+    rowptr, col = ref_numpy.coo_to_csr(np.stack([dst, src], 1), n)
+    ref = np.stack([wh[col[rowptr[i]:rowptr[i + 1]]].mean(0) for i in range(n)])
+    assert_close(out, ref, what="uniform attention")
+    g1 = CSRGraph.from_coo(np.array([0]), np.array([0]), 1, dev)
+    o1 = ops.sparse_gat_layer(torch.tensor(x[:1], device=dev), torch.tensor(W, device=dev),
+                              torch.ones(H, D, device=dev), torch.ones(H, D, device=dev), z(H), z(H), z(H, D), g1, cfg)
+    assert_close(o1.cpu().numpy(), wh[:1], what="single node")

@@ -1,0 +1,61 @@
+"""Shared helpers of the parity tests: seeded inputs and the comparison rule."""
+import numpy as np
+
+
+def random_graph(n, avg_deg, seed, directed=True, hubs=0, hub_deg=0):
+    """COO (dst, src) with distinct pairs and one self-loop per node (process.py:181 adds them)."""
+    rng = np.random.default_rng(seed)
+    m = int(n * avg_deg)
+    dst = rng.integers(0, n, m)
+    src = rng.integers(0, n, m)
+    if hubs:
+        hd = rng.integers(0, n, hubs)
+        for h in hd:
+            k = min(hub_deg, n)
+            nb = rng.choice(n, size=k, replace=False)
+            dst = np.concatenate([dst, np.full(k, h)])
+            src = np.concatenate([src, nb])
+            # and the transpose so that out-degrees are skewed too
+            dst = np.concatenate([dst, nb])
+            src = np.concatenate([src, np.full(k, h)])
+    if not directed:
+        dst, src = np.concatenate([dst, src]), np.concatenate([src, dst])
+    dst = np.concatenate([dst, np.arange(n)])
+    src = np.concatenate([src, np.arange(n)])
+    key = np.unique(dst.astype(np.int64) * n + src)
+    return (key // n).astype(np.int32), (key % n).astype(np.int32)
+
+
+def layer_params(F, H, D, seed, res=False, dtype=np.float64):
+    """Explicit weights (parity never depends on initialisers).  Biases are non-zero on purpose."""
+    rng = np.random.default_rng(seed)
+    lim_w = np.sqrt(6.0 / (F + D))
+    lim_a = np.sqrt(6.0 / (D + 1))
+    p = {
+        "W": rng.uniform(-lim_w, lim_w, (F, H, D)),
+        "a1": rng.uniform(-lim_a, lim_a, (H, D)),
+        "a2": rng.uniform(-lim_a, lim_a, (H, D)),
+        "b1": rng.normal(0, 0.1, H),
+        "b2": rng.normal(0, 0.1, H),
+        "bias": rng.normal(0, 0.1, (H, D)),
+    }
+    if res:
+        p["W_res"] = rng.uniform(-lim_w, lim_w, (F, H, D))
+        p["b_res"] = rng.normal(0, 0.1, (H, D))
+    return {k: v.astype(dtype) for k, v in p.items()}
+
+
+def assert_close(got, ref, rtol=1e-5, atol_scale=2e-6, what=""):
+    """|got - ref| <= rtol*|ref| + atol_scale*max|ref| elementwise (fp32 kernels vs an fp64 oracle:
+    the summation order differs, so an absolute term relative to the tensor's scale is needed)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, "%s: shape %s vs %s" % (what, got.shape, ref.shape)
+    scale = float(np.max(np.abs(ref))) if ref.size else 0.0
+    err = np.abs(got - ref)
+    tol = rtol * np.abs(ref) + atol_scale * scale + 1e-30
+    bad = err > tol
+    if bad.any():
+        k = np.unravel_index(np.argmax(err / tol), err.shape)
+        raise AssertionError("%s: %d/%d elements out of tolerance; worst at %s got %.9g ref %.9g (err %.3g, tol %.3g, scale %.3g)"
+                             % (what, bad.sum(), bad.size, k, got[k], ref[k], err[k], tol[k], scale))
