@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Benchmark of the graph-attention hot path: one 8-head GAT layer, forward + backward.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (N = 1): BASELINE.json configs[3] — a synthetic power-law (R-MAT) graph at the
+ogbn-products shape, 2,449,029 nodes, 61,859,140 directed edges + one self-loop per node,
+100 input features, 8 heads x 8 hidden, ELU, fp32.  A step = forward + backward of the layer
+(all parameter gradients; no dX, it is a first layer), inputs resident in HBM, dropout off.
+For N > 1 every rank owns a products-sized block of destination rows of an N-times larger
+R-MAT graph (weak scaling) and exchanges halo rows with RCCL all-to-all.
+
+Prints ONE JSON line on rank 0.  `value` = directed edge entries (self-loops included)
+processed per second over all ranks.  `roofline` prices the slowest kernel of the step against
+the 8 TB/s HBM peak from algorithmic bytes; `layer_roofline` does the same for the whole step
+with the survey's byte model (944 B/edge + 2984 B/node at these dimensions).
+`cpu_baseline` times the CPU restatement of the reference math (oracle/ref_torch.py, labelled
+"port": TensorFlow, which the reference runs on, is not installed) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0
+F_IN, HEADS, WIDTH = 100, 8, 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nodes", type=int, default=0, help="override node count per GPU (debug)")
+    ap.add_argument("--edges", type=int, default=0, help="override edge count per GPU (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk", type=int, default=0)
+    return ap.parse_args()
+
+
+def layer_alg_bytes(E, N, f_in=F_IN, H=HEADS, D=WIDTH, s=4):
+    """Survey byte model of one layer fwd+bwd (gather-inclusive)."""
+    per_edge = 3 * H * D * s + 3 * H * 4 + 2 * H * 4 + 16
+    per_node = 8 * f_in + 7 * H * D * 4 + 12 * H * 4 + 8
+    return E * per_edge + N * per_node
+
+
+def kernel_alg_bytes(name, E, N, H=HEADS, D=WIDTH, f_in=F_IN):
+    """Algorithmic bytes of one launch of each entry point (what the math must touch once)."""
+    hd = H * D * 4
+    if name == "gatmi_gat_fwd":       # gather Wh row + f2 + col id per edge; f1, item, out per node
+        return E * (hd + H * 4 + 4) + N * (hd + H * 4 + 16)
+    if name == "gatmi_gat_bwd_csc":   # gather g row + {f1,lse,c} + row id per edge; Wh, f2, df1 in, dWh, df2 out per node
+        return E * (hd + 3 * H * 4 + 4) + N * (2 * hd + 3 * H * 4 + 16)
+    if name == "gatmi_gat_bwd_node":  # dOut, out, agg, pos in; g out; small per-head vectors
+        return N * (5 * hd + 8 * H * 4)
+    if name == "gatmi_proj_fwd":
+        return N * (f_in * 4 + hd + 2 * H * 4)
+    if name == "gatmi_proj_bwd_params":
+        return N * (f_in * 4 + 2 * hd + 2 * H * 4)
+    return 0
+
+
+class EventProfiler:
+    """HIP events (torch's current stream = the stream the kernels are enqueued on) around every
+    C-ABI call; durations are read after the timed region."""
+
+    def __init__(self):
+        self.records = {}
+
+    def wrap(self, call):
+        def timed(name, *args):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            call(name, *args)
+            b.record()
+            self.records.setdefault(name, []).append((a, b))
+        return timed
+
+    def summary(self):
+        out = {}
+        for name, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = (sum(ms) / len(ms), len(ms))
+        return out
+
+
+def cpu_baseline(sample_nodes=272_114, sample_edges=6_873_238, iters=2):
+    """The CPU restatement (oracle) on an R-MAT sample with the benchmark's average degree."""
+    from oracle import ref_torch
+    from gat_amd import synth
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    dst, src = synth.rmat_graph(sample_nodes, sample_edges, 4, torch.device("cpu"))
+    order = torch.argsort(dst * sample_nodes + src)
+    dst, src = dst[order], src[order]
+    rowptr = torch.zeros(sample_nodes + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=sample_nodes), 0)
+    p = synth.glorot_layer(F_IN, HEADS, WIDTH, 7, torch.device("cpu"))
+    x = synth.normal((sample_nodes, F_IN), 5, torch.device("cpu"))
+    dout = synth.normal((sample_nodes, HEADS * WIDTH), 8, torch.device("cpu"))
+    for v in p.values():
+        v.requires_grad_(True)
+    best = None
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        out = ref_torch.layer_csr(x, p, rowptr, src.to(torch.int32), "elu", "concat")
+        out.backward(dout)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        for v in p.values():
+            v.grad = None
+    E = int(dst.numel())
+    return {"value": E / best, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": "R-MAT %d nodes / %d edge entries (benchmark's average degree), fp32 torch-CPU restatement "
+                      "of utils/layers.py:6-34 on stored edges, best of %d fwd+bwd" % (sample_nodes, E, iters)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the graph-attention kernels have no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import gat_amd
+    from gat_amd import _lib, synth, CSRGraph
+    from gat_amd.layers import GATHeads
+
+    n_own = args.nodes or synth.PRODUCTS_NODES
+    e_own = args.edges or synth.PRODUCTS_EDGES
+    chunk = args.chunk or gat_amd.graph.DEFAULT_CHUNK
+
+    if world > 1:
+        import torch.distributed as dist
+        from gat_amd import dist as gdist
+        dist.init_process_group("nccl", device_id=dev)
+        layer_step, E_rank, info = gdist.build_bench_step(rank, world, n_own, e_own, F_IN, HEADS, WIDTH, dev, chunk)
+    else:
+        dst, src = synth.rmat_graph(n_own, e_own, 4, dev)
+        graph = CSRGraph.from_device_coo(dst, src, n_own, n_own, chunk=chunk)
+        del dst, src
+        E_rank = graph.nnz
+        x = synth.normal((n_own, F_IN), 5, dev)
+        dout = synth.normal((n_own, HEADS * WIDTH), 8, dev)
+        heads = GATHeads(F_IN, HEADS, WIDTH, device=dev)
+        heads.load(synth.glorot_layer(F_IN, HEADS, WIDTH, 7, dev))
+        heads.train()
+        params = list(heads.parameters())
+        info = {"graph": repr(graph)}
+
+        def layer_step():
+            for p in params:
+                p.grad = None
+            out = heads(x, graph, "elu", "concat")
+            out.backward(dout)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        layer_step()
+    prof = EventProfiler()
+    raw_call = _lib.call
+    _lib.call = prof.wrap(raw_call)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        layer_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.call = raw_call
+
+    t = torch.tensor([elapsed, float(E_rank)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+        elapsed, E_total = float(tmax[0]), float(t[1])
+    else:
+        E_total = float(E_rank)
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank == 0:
+        ksum = prof.summary()
+        dom = max(ksum, key=lambda k: ksum[k][0]) if ksum else None
+        roofline = None
+        if dom:
+            ab = kernel_alg_bytes(dom, E_rank, n_own)
+            gbps = ab / (ksum[dom][0] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                        "alg_bytes_per_launch": ab, "avg_ms": round(ksum[dom][0], 4)}
+        lb = layer_alg_bytes(E_rank, n_own)
+        lg = lb / (ms_per_step * 1e-3) / 1e9
+        line = {
+            "metric": "GAT layer fwd+bwd edges/sec (8 heads) + % HBM roofline at 1/2/4/8 GPUs",
+            "value": E_total / (ms_per_step * 1e-3), "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "R-MAT power-law graph at ogbn-products shape per GPU: %d nodes, %d edge entries "
+                                   "(self-loops included), %d-d features, %d heads x %d, ELU, fwd+bwd of one layer"
+                                   % (n_own, E_rank, F_IN, HEADS, WIDTH),
+                       "partitioning": "single GPU" if world == 1 else "row-partitioned x%d, RCCL halo all-to-all" % world},
+            "roofline": roofline,
+            "layer_roofline": {"bound": "hbm", "alg_bytes": lb, "achieved": round(lg, 1), "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": round(lg / HBM_PEAK_GBPS, 4)},
+            "kernels_ms": {k: round(v[0], 4) for k, v in sorted(ksum.items())},
+            "info": info,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

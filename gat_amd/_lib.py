@@ -6,6 +6,12 @@ a non-zero return code into RuntimeError carrying gatmi_last_error().
 """
 import ctypes
 import os
+
+# PyTorch-ROCm ships its own HIP runtime (soname libamdhip64.so.7).  It must be in the process
+# before libgatmi.so is opened, so that the kernels are launched through the same runtime instance
+# that owns torch's device memory and streams; loading libgatmi first would map a second runtime.
+import torch  # noqa: F401  (isort: keep above the CDLL call)
+
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -88,5 +94,4 @@ def ptr(t):
 
 
 def current_stream():
-    import torch
     return torch.cuda.current_stream().cuda_stream

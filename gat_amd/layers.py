@@ -1,0 +1,178 @@
+"""Drop-in surface of the reference's utils/layers.py for the graph-attention head.
+
+    attn_head(seq, out_sz, bias_mat, activation, in_drop=0.0, coef_drop=0.0, residual=False)
+        — utils/layers.py:6, dense [B,N,F] input with an additive [B,N,N] mask
+    sp_attn_head(seq, out_sz, adj_mat, activation, nb_nodes, in_drop=0.0, coef_drop=0.0, residual=False)
+        — called at models/sp_gat.py:13-16 (its body is absent from the reference tree); batch 1
+
+TensorFlow 1 creates a layer's variables implicitly, in call order, every time the graph is built
+(tf.layers.conv1d at layers.py:11,14,15,30; bias_add at :25).  Here the variables live in a
+VariableStore that hands them out in the same call order: the first pass creates them (Glorot
+uniform kernels, zero biases — the TF defaults), later passes reuse them.  `attn_heads` /
+`sp_attn_heads` are the fused form of n_heads consecutive calls followed by tf.concat or
+tf.add_n / n (models/sp_gat.py:12-17, 27-32): one kernel sweep for all heads.
+"""
+import contextlib
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .graph import CSRGraph
+
+elu = "elu"
+identity = "identity"
+
+
+def _activation_name(activation):
+    """Accept the reference's callables (tf.nn.elu, lambda x: x) by name, or our string names."""
+    if activation in ("elu", "identity", None):
+        return activation or "identity"
+    name = getattr(activation, "__name__", "")
+    if name == "elu":
+        return "elu"
+    if name == "<lambda>" or name == "identity":
+        return "identity"
+    raise ValueError("unsupported activation %r: the kernels fuse ELU or the identity" % (activation,))
+
+
+class GATHeads(nn.Module):
+    """Parameters of H attention heads of width D over F input features (one `attn_head` call
+    per head in the reference).  W [F,H,D] <- conv1d(seq, out_sz, 1, use_bias=False) kernels;
+    a1/a2 [H,D], b1/b2 [H] <- the two conv1d(seq_fts, 1, 1); bias [H,D] <- bias_add;
+    W_res/b_res <- the residual conv1d (layers.py:30), present only when residual and F != D."""
+
+    def __init__(self, f_in, heads, width, residual=False, device=None):
+        super().__init__()
+        self.f_in, self.heads, self.width = int(f_in), int(heads), int(width)
+        kw = {"device": device, "dtype": torch.float32}
+        self.W = nn.Parameter(torch.empty(f_in, heads, width, **kw))
+        self.a1 = nn.Parameter(torch.empty(heads, width, **kw))
+        self.a2 = nn.Parameter(torch.empty(heads, width, **kw))
+        self.b1 = nn.Parameter(torch.zeros(heads, **kw))
+        self.b2 = nn.Parameter(torch.zeros(heads, **kw))
+        self.bias = nn.Parameter(torch.zeros(heads, width, **kw))
+        self.has_res = bool(residual) and f_in != width      # layers.py:29: no-op when widths agree
+        if self.has_res:
+            self.W_res = nn.Parameter(torch.empty(f_in, heads, width, **kw))
+            self.b_res = nn.Parameter(torch.zeros(heads, width, **kw))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        lim_w = math.sqrt(6.0 / (self.f_in + self.width))
+        lim_a = math.sqrt(6.0 / (self.width + 1))
+        with torch.no_grad():
+            self.W.uniform_(-lim_w, lim_w)
+            self.a1.uniform_(-lim_a, lim_a)
+            self.a2.uniform_(-lim_a, lim_a)
+            if self.has_res:
+                self.W_res.uniform_(-lim_w, lim_w)
+
+    def load(self, params):
+        """Copy explicit weights (dict of array-likes with the parameter names)."""
+        with torch.no_grad():
+            for k, v in params.items():
+                getattr(self, k).copy_(torch.as_tensor(v, dtype=torch.float32))
+
+    def forward(self, seq, graph_or_bias, activation="elu", reduce="concat", in_drop=0.0, coef_drop=0.0,
+                training=None, seed=None):
+        training = self.training if training is None else training
+        H, D = self.heads, self.width
+        act = _activation_name(activation)
+        if training and in_drop > 0.0:
+            seq = torch.nn.functional.dropout(seq, in_drop, True)            # layers.py:8-9
+        wr = self.W_res if self.has_res else None
+        br = self.b_res if self.has_res else None
+        if isinstance(graph_or_bias, CSRGraph):
+            x = seq[0] if seq.dim() == 3 else seq                           # batch is 1 on the sparse path
+            if not ops.supported_shape(H, D):
+                raise ValueError("heads=%d width=%d not supported by the fused kernels" % (H, D))
+            cfg = ops.make_cfg(H, D, act, reduce, coef_drop, in_drop, training, seed)
+            out = ops.sparse_gat_layer(x, self.W, self.a1, self.a2, self.b1, self.b2, self.bias, graph_or_bias, cfg, wr, br)
+            return out[None] if seq.dim() == 3 else out
+        cfg = ops.make_cfg(H, D, act, "concat", coef_drop, in_drop, training, seed)
+        out = ops.dense_gat_layer(seq, self.W, self.a1, self.a2, self.b1, self.b2, self.bias, graph_or_bias, cfg, wr, br)
+        if reduce == "mean":
+            B, N = out.shape[:2]
+            out = out.reshape(B, N, H, D).mean(2)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# TF1-style implicit variables
+# ------------------------------------------------------------------------------------------------
+class VariableStore(nn.Module):
+    """Hands out GATHeads modules in call order, creating them on the first pass."""
+
+    def __init__(self):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        self._cursor = 0
+
+    def begin(self):
+        self._cursor = 0
+
+    def next_heads(self, f_in, heads, width, residual, device):
+        if self._cursor == len(self.layers):
+            self.layers.append(GATHeads(f_in, heads, width, residual, device))
+        m = self.layers[self._cursor]
+        if (m.f_in, m.heads, m.width) != (f_in, heads, width):
+            raise ValueError("variable %d was created for (f_in,heads,width)=%s, now asked for %s"
+                             % (self._cursor, (m.f_in, m.heads, m.width), (f_in, heads, width)))
+        self._cursor += 1
+        return m
+
+
+_default_store = VariableStore()
+_active = [_default_store]
+
+
+def default_store():
+    return _active[-1]
+
+
+@contextlib.contextmanager
+def variable_scope(store):
+    """Route the implicit variables of attn_head / sp_attn_head calls to `store`."""
+    _active.append(store)
+    try:
+        yield store
+    finally:
+        _active.pop()
+
+
+def _graph_of(adj_mat, device):
+    if isinstance(adj_mat, CSRGraph):
+        return adj_mat
+    return CSRGraph.from_reference_triple(adj_mat, device)
+
+
+def attn_heads(seq, out_sz, bias_mat, activation, n_heads, reduce="concat", in_drop=0.0, coef_drop=0.0,
+               residual=False, training=True):
+    m = default_store().next_heads(seq.shape[-1], n_heads, out_sz, residual, seq.device)
+    return m(seq, bias_mat, activation, reduce, in_drop, coef_drop, training)
+
+
+def sp_attn_heads(seq, out_sz, adj_mat, activation, nb_nodes, n_heads, reduce="concat", in_drop=0.0,
+                  coef_drop=0.0, residual=False, training=True):
+    graph = _graph_of(adj_mat, seq.device)
+    if graph.n_dst != nb_nodes:
+        raise ValueError("nb_nodes=%d but adj_mat has %d rows" % (nb_nodes, graph.n_dst))
+    m = default_store().next_heads(seq.shape[-1], n_heads, out_sz, residual, seq.device)
+    return m(seq, graph, activation, reduce, in_drop, coef_drop, training)
+
+
+def attn_head(seq, out_sz, bias_mat, activation, in_drop=0.0, coef_drop=0.0, residual=False):
+    """utils/layers.py:6.  seq [B,N,F], bias_mat [B,N,N] additive mask; returns [B,N,out_sz].
+    As in the reference, a non-zero dropout rate means "training" (layers.py:8,19,21 test the rate
+    itself; evaluation feeds 0.0, execute_cora.py:123)."""
+    training = in_drop != 0.0 or coef_drop != 0.0
+    return attn_heads(seq, out_sz, bias_mat, activation, 1, "concat", in_drop, coef_drop, residual, training)
+
+
+def sp_attn_head(seq, out_sz, adj_mat, activation, nb_nodes, in_drop=0.0, coef_drop=0.0, residual=False):
+    """Signature of the call at models/sp_gat.py:13-16.  seq [1,N,F]; adj_mat is the
+    (indices, values, shape) triple of preprocess_adj_bias (utils/process.py:188) or a CSRGraph."""
+    training = in_drop != 0.0 or coef_drop != 0.0
+    return sp_attn_heads(seq, out_sz, adj_mat, activation, nb_nodes, 1, "concat", in_drop, coef_drop, residual, training)
