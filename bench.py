@@ -132,6 +132,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the graph-attention kernels have no CPU path")
+    # GATMI_DIST_BACKEND=gloo rehearses N > 1 on a box with fewer GPUs than ranks (ranks share devices,
+    # buffers are staged through the host); the measured configuration is always nccl = RCCL.
+    backend = os.environ.get("GATMI_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -146,7 +150,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         from gat_amd import dist as gdist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         layer_step, E_rank, info = gdist.build_bench_step(rank, world, n_own, e_own, F_IN, HEADS, WIDTH, dev, chunk)
     else:
         dst, src = synth.rmat_graph(n_own, e_own, 4, dev)
@@ -213,6 +220,7 @@ def main():
             "value": E_total / (ms_per_step * 1e-3), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
             "config": {"workload": "R-MAT power-law graph at ogbn-products shape per GPU: %d nodes, %d edge entries "
                                    "(self-loops included), %d-d features, %d heads x %d, ELU, fwd+bwd of one layer"
                                    % (n_own, E_rank, F_IN, HEADS, WIDTH),

@@ -438,6 +438,28 @@ __global__ __launch_bounds__(256) void gat_bwd_merge_kernel(BwdCscArgs a, const 
     bwd_finish<G, LPH, DROP>(st, a, rec.x, sub, head);
 }
 
+// dfeat_j += df1_j * a1 + df2_j * a2 for owned rows, after halo contributions have been added
+// (row-partitioned runs keep this step out of the per-source kernel).
+template <int G, int LPH>
+__global__ __launch_bounds__(256) void gat_bwd_finalize_kernel(int64_t n, const float *df1, const float *df2,
+                                                                const float *a1, const float *a2, float *dfeat) {
+    constexpr int RPW = 64 / G;
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, grp = lane / G;
+    const int head = sub / LPH;
+    const float4 a1v = *reinterpret_cast<const float4 *>(a1 + sub * 4);
+    const float4 a2v = *reinterpret_cast<const float4 *>(a2 + sub * 4);
+    const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+    for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp; row < n; row += stride) {
+        float4 r = *reinterpret_cast<const float4 *>(dfeat + row * HD + sub * 4);
+        r = f4_fma(df1[row * H + head], a1v, r);
+        r = f4_fma(df2[row * H + head], a2v, r);
+        *reinterpret_cast<float4 *>(dfeat + row * HD + sub * 4) = r;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side dispatch over (G, LPH)
 // ------------------------------------------------------------------------------------------
@@ -501,9 +523,35 @@ static int launch_bwd_csc(const BwdCscArgs &a, const int4 *split, int64_t n_spli
     return GATMI_OK;
 }
 
+template <int G, int LPH>
+static int launch_bwd_finalize(int64_t n, const float *df1, const float *df2, const float *a1, const float *a2,
+                               float *dfeat, hipStream_t st) {
+    const int64_t per_block = 4 * (64 / G);
+    const unsigned nb = (unsigned)std::min<int64_t>(4096, std::max<int64_t>(1, (n + per_block - 1) / per_block));
+    hipLaunchKernelGGL((gat_bwd_finalize_kernel<G, LPH>), dim3(nb), dim3(256), 0, st, n, df1, df2, a1, a2, dfeat);
+    GATMI_LAUNCH_CHECK("gat_bwd_finalize");
+    return GATMI_OK;
+}
+
 }  // namespace gatmi
 
 using namespace gatmi;
+
+extern "C" int gatmi_gat_bwd_finalize(int64_t n, int32_t H, int32_t dp, const float *df1, const float *df2,
+                                      const float *a1, const float *a2, float *dfeat, void *stream) {
+    int G, LPH;
+    int rc = check_shape(H, dp, &G, &LPH);
+    if (rc) return rc;
+    GATMI_REQUIRE(n >= 0, GATMI_EINVAL, "gat_bwd_finalize: negative size");
+    if (n == 0) return GATMI_OK;
+    GATMI_REQUIRE(df1 && df2 && a1 && a2 && dfeat, GATMI_EINVAL, "gat_bwd_finalize: null pointer");
+    GATMI_REQUIRE_ALIGNED(a1); GATMI_REQUIRE_ALIGNED(a2); GATMI_REQUIRE_ALIGNED(dfeat);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define X(gg, l) if (G == gg && LPH == l) return launch_bwd_finalize<gg, l>(n, df1, df2, a1, a2, dfeat, st);
+    GATMI_FOR_SHAPES(X)
+#undef X
+    return fail(GATMI_EUNSUPPORTED, "gat_bwd_finalize: no kernel for H=%d dp=%d", H, dp);
+}
 
 extern "C" size_t gatmi_gat_fwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp) {
     if (n_slots <= 0) return 0;

@@ -35,24 +35,39 @@ __global__ __launch_bounds__(256) void halo_unpack_add_kernel(const float *src, 
     }
 }
 
+// any width: one float per lane (narrow rows such as f2 [n, H] with H < 4)
+__global__ __launch_bounds__(256) void halo_pack_scalar_kernel(const float *src, const int64_t *idx, int64_t n_idx,
+                                                                int w, float *dst) {
+    const int64_t total = n_idx * w;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+        dst[e] = src[idx[e / w] * w + e % w];
+}
+
+__global__ __launch_bounds__(256) void halo_unpack_add_scalar_kernel(const float *src, const int64_t *idx,
+                                                                      int64_t n_idx, int w, float *dst) {
+    const int64_t total = n_idx * w;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+        dst[idx[e / w] * w + e % w] += src[e];
+}
+
 }  // namespace gatmi
 
 using namespace gatmi;
 
 static int halo_common(const float *src, const int64_t *idx, int64_t n_idx, int32_t width, float *dst, const char *name) {
-    GATMI_REQUIRE(n_idx >= 0 && width > 0 && width % 4 == 0, GATMI_EINVAL, "%s: width=%d must be a positive multiple of 4", name, width);
+    GATMI_REQUIRE(n_idx >= 0 && width > 0, GATMI_EINVAL, "%s: width=%d must be positive", name, width);
     GATMI_REQUIRE(n_idx == 0 || (src && idx && dst), GATMI_EINVAL, "%s: null pointer", name);
-    GATMI_REQUIRE_ALIGNED(src);
-    GATMI_REQUIRE_ALIGNED(dst);
     return GATMI_OK;
 }
 
 extern "C" int gatmi_halo_pack(const float *src, const int64_t *idx, int64_t n_idx, int32_t width, float *dst, void *stream) {
     int rc = halo_common(src, idx, n_idx, width, dst, "halo_pack");
     if (rc || n_idx == 0) return rc;
-    const int64_t total = n_idx * (width / 4);
+    const bool vec = width % 4 == 0 && aligned16(src) && aligned16(dst);
+    const int64_t total = vec ? n_idx * (width / 4) : n_idx * width;
     const unsigned nb = (unsigned)std::min<int64_t>(4096, (total + 255) / 256);
-    hipLaunchKernelGGL(halo_pack_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, idx, n_idx, width / 4, dst);
+    if (vec) hipLaunchKernelGGL(halo_pack_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, idx, n_idx, width / 4, dst);
+    else hipLaunchKernelGGL(halo_pack_scalar_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, idx, n_idx, width, dst);
     GATMI_LAUNCH_CHECK("halo_pack");
     return GATMI_OK;
 }
@@ -60,9 +75,11 @@ extern "C" int gatmi_halo_pack(const float *src, const int64_t *idx, int64_t n_i
 extern "C" int gatmi_halo_unpack_add(const float *src, const int64_t *idx, int64_t n_idx, int32_t width, float *dst, void *stream) {
     int rc = halo_common(src, idx, n_idx, width, dst, "halo_unpack_add");
     if (rc || n_idx == 0) return rc;
-    const int64_t total = n_idx * (width / 4);
+    const bool vec = width % 4 == 0 && aligned16(src) && aligned16(dst);
+    const int64_t total = vec ? n_idx * (width / 4) : n_idx * width;
     const unsigned nb = (unsigned)std::min<int64_t>(4096, (total + 255) / 256);
-    hipLaunchKernelGGL(halo_unpack_add_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, idx, n_idx, width / 4, dst);
+    if (vec) hipLaunchKernelGGL(halo_unpack_add_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, idx, n_idx, width / 4, dst);
+    else hipLaunchKernelGGL(halo_unpack_add_scalar_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, idx, n_idx, width, dst);
     GATMI_LAUNCH_CHECK("halo_unpack_add");
     return GATMI_OK;
 }

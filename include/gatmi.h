@@ -182,6 +182,12 @@ int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
                       float slope, float coef_keep, float feat_keep, uint64_t seed,
                       float *dfeat, float *df2, float *ws, void *stream);
 
+/* Last step of the backward pass for owned rows when gatmi_gat_bwd_csc ran with a1 == NULL
+ * (row-partitioned runs add the peers' halo contributions to dfeat / df2 first):
+ *   dfeat[j,:] += df1[j,h] * a1 + df2[j,h] * a2   — the gradient of layers.py:14-15 w.r.t. seq_fts. */
+int gatmi_gat_bwd_finalize(int64_t n, int32_t H, int32_t dp, const float *df1, const float *df2,
+                           const float *a1, const float *a2, float *dfeat, void *stream);
+
 /* Batched dense masked attention (small graphs).  Replaces utils/layers.py:16-25,34 on
  * [B, N, *] tensors with the additive bias_mat [B, N, N] of utils/process.py:14-25 (any additive
  * values, not only 0 / -1e9).
@@ -201,7 +207,8 @@ int gatmi_dense_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t dp,
                          float slope, float *dWh, float *df2, void *stream);
 
 /* Halo exchange helpers (row-partitioned multi-GPU).  pack: dst[k, :] = src[idx[k], :] for
- * k < n_idx, rows of `width` floats (send buffer of Wh / f2 rows requested by a peer).
+ * k < n_idx, rows of `width` floats (send buffer of Wh / f2 rows requested by a peer); rows are
+ * moved 16 bytes per lane when width is a multiple of 4, one float per lane otherwise.
  * unpack_add: dst[idx[k], :] += src[k, :] (gradient rows returned by a peer; idx may repeat
  * across peers but not inside one call). */
 int gatmi_halo_pack(const float *src, const int64_t *idx, int64_t n_idx, int32_t width,
