@@ -1,0 +1,89 @@
+"""Coefficient and feature dropout inside the CSR kernels (utils/layers.py:20,22).
+
+TensorFlow's random stream is not a parity target; what is checked is (1) that the kernels'
+counter-based masks, replayed on the host with the same hash, give the oracle's result with
+explicit masks — forward and every gradient, so forward and backward saw the same mask;
+(2) rate 0 is an exact identity; (3) the keep frequency matches the rate."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_numpy, ref_torch
+from tests.util import assert_close, layer_params, random_graph
+
+pytestmark = pytest.mark.gpu
+
+FEAT_SALT = 0x5DEECE66D
+
+
+def keep_mask_host(seed, idx, keep):
+    """Host twin of keep_mask in gat_amd/csrc/device_common.h (splitmix64 finaliser, top 24 bits)."""
+    with np.errstate(over="ignore"):
+        z = idx.astype(np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    r = (z >> np.uint64(40)).astype(np.float32)
+    return (r * np.float32(1.0 / 16777216.0)) < np.float32(keep)
+
+
+@pytest.mark.parametrize("H,D,coef_drop,in_drop", [(8, 8, 0.6, 0.6), (1, 7, 0.3, 0.0), (4, 8, 0.0, 0.5)])
+def test_masks_replay_in_forward_and_backward(H, D, coef_drop, in_drop):
+    from gat_amd import CSRGraph, ops
+    dev = torch.device("cuda:0")
+    n, F = 300, 16
+    dp = ops.padded_width(D)
+    dst, src = random_graph(n, 6.0, seed=H, hubs=2, hub_deg=200)
+    rowptr, col = ref_numpy.coo_to_csr(np.stack([dst, src], 1), n)
+    E = len(col)
+    p = layer_params(F, H, D, seed=3)
+    x = np.random.default_rng(4).normal(0, 1, (n, F))
+    seed = 123456789
+    tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+    xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
+    cfg = ops.make_cfg(H, D, "elu", "concat", coef_drop=coef_drop, in_drop=in_drop, training=True, seed=seed)
+    graph = CSRGraph.from_coo(dst, src, n, dev, chunk=64)
+    out = ops.sparse_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], graph, cfg)
+    dout = np.random.default_rng(5).normal(0, 1, tuple(out.shape))
+    out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
+
+    coef_mask = ft_mask = None
+    if coef_drop > 0:
+        idx = (np.arange(E, dtype=np.uint64)[:, None] * np.uint64(H) + np.arange(H, dtype=np.uint64)[None, :])
+        coef_mask = keep_mask_host(seed, idx, 1.0 - coef_drop).astype(np.float64)
+        assert abs(coef_mask.mean() - (1.0 - coef_drop)) < 0.03
+    if in_drop > 0:
+        cols = (np.arange(H)[:, None] * dp + np.arange(D)[None, :]).astype(np.uint64)          # padded column ids
+        idx = np.arange(n, dtype=np.uint64)[:, None, None] * np.uint64(H * dp) + cols[None]
+        ft_mask = keep_mask_host(seed ^ FEAT_SALT, idx, 1.0 - in_drop).astype(np.float64)
+        assert abs(ft_mask.mean() - (1.0 - in_drop)) < 0.03
+    rp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = ref_torch.layer_csr(rx, rp, torch.tensor(rowptr), torch.tensor(col), "elu", "concat",
+                              coef_mask=None if coef_mask is None else torch.tensor(coef_mask),
+                              ft_mask=None if ft_mask is None else torch.tensor(ft_mask),
+                              coef_keep=1.0 - coef_drop, ft_keep=1.0 - in_drop)
+    ref.backward(torch.tensor(dout))
+    assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), what="forward with dropout")
+    assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what="dX")
+    for k in ("W", "a1", "a2", "bias"):
+        assert_close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), atol_scale=5e-6, what="d" + k)
+
+
+def test_rate_zero_and_eval_are_exact_identities():
+    from gat_amd import CSRGraph, ops
+    dev = torch.device("cuda:0")
+    n, F, H, D = 150, 10, 8, 8
+    dst, src = random_graph(n, 4.0, seed=9)
+    p = layer_params(F, H, D, seed=1)
+    tp = {k: torch.tensor(v, dtype=torch.float32, device=dev) for k, v in p.items()}
+    x = torch.randn(n, F, device=dev)
+    g = CSRGraph.from_coo(dst, src, n, dev)
+    run = lambda cfg: ops.sparse_gat_layer(x, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], g, cfg)
+    base = run(ops.make_cfg(H, D, "elu"))
+    assert torch.equal(base, run(ops.make_cfg(H, D, "elu", coef_drop=0.0, in_drop=0.0, training=True)))
+    assert torch.equal(base, run(ops.make_cfg(H, D, "elu", coef_drop=0.6, in_drop=0.6, training=False)))
+    dropped = run(ops.make_cfg(H, D, "elu", coef_drop=0.6, in_drop=0.6, training=True, seed=5))
+    assert not torch.equal(base, dropped)
+    assert torch.equal(dropped, run(ops.make_cfg(H, D, "elu", coef_drop=0.6, in_drop=0.6, training=True, seed=5)))
+    assert not torch.equal(dropped, run(ops.make_cfg(H, D, "elu", coef_drop=0.6, in_drop=0.6, training=True, seed=6)))
