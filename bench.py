@@ -145,7 +145,7 @@ def main():
 
     n_own = args.nodes or synth.PRODUCTS_NODES
     e_own = args.edges or synth.PRODUCTS_EDGES
-    chunk = args.chunk or gat_amd.graph.DEFAULT_CHUNK
+    chunk = args.chunk
 
     if world > 1:
         import torch.distributed as dist

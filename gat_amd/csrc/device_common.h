@@ -38,6 +38,25 @@ __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x)
 // derivative of ELU written in terms of its OUTPUT y: 1 for y > 0, y + 1 (= exp(x)) otherwise
 __device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
 
+// Fixed-order column sum of per-block partial results.  Launch with dim3(64, 16) threads: thread
+// (cx, ry) adds rows ry, ry+16, ... of its column, the 16 partial sums meet in LDS and row 0 adds
+// them in order, so the result does not depend on scheduling.  `load(r)` returns row r's value.
+constexpr int kSumCols = 64, kSumRows = 16;
+template <typename Load>
+__device__ __forceinline__ float block_column_sum(int rows, Load load) {
+    __shared__ float part[kSumRows][kSumCols];
+    float t = 0.f;
+    for (int r = threadIdx.y; r < rows; r += kSumRows) t += load(r);
+    part[threadIdx.y][threadIdx.x] = t;
+    __syncthreads();
+    float total = 0.f;
+    if (threadIdx.y == 0) {
+#pragma unroll
+        for (int k = 0; k < kSumRows; ++k) total += part[k][threadIdx.x];
+    }
+    return total;
+}
+
 }  // namespace gatmi
 
 #define GATMI_LAUNCH_CHECK(name)                                                         \

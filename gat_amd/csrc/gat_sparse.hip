@@ -298,11 +298,10 @@ __global__ __launch_bounds__(256) void gat_bwd_node_kernel(BwdNodeArgs a) {
 
 // out[c] = sum over `rows` partial rows of ws[r][c] (fixed order => reproducible)
 __global__ void column_sum_kernel(const float *ws, int rows, int width, float *out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
-    float t = 0.f;
-    for (int r = 0; r < rows; ++r) t += ws[(int64_t)r * width + c];
-    out[c] = t;
+    const int c = blockIdx.x * kSumCols + threadIdx.x;
+    const bool ok = c < width;
+    const float t = block_column_sum(rows, [&](int r) { return ok ? ws[(int64_t)r * width + c] : 0.f; });
+    if (ok && threadIdx.y == 0) out[c] = t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -500,7 +499,7 @@ static int launch_bwd_node(const BwdNodeArgs &a, float *dbias, hipStream_t st) {
     hipLaunchKernelGGL((gat_bwd_node_kernel<G, LPH>), dim3(nb), dim3(256), 0, st, a);
     GATMI_LAUNCH_CHECK("gat_bwd_node");
     if (dbias) {
-        hipLaunchKernelGGL(column_sum_kernel, dim3((HD + 63) / 64), dim3(64), 0, st, a.ws, (int)nb, HD, dbias);
+        hipLaunchKernelGGL(column_sum_kernel, dim3((HD + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, a.ws, (int)nb, HD, dbias);
         GATMI_LAUNCH_CHECK("gat_bwd_node dbias");
     }
     return GATMI_OK;

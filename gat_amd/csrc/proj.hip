@@ -176,6 +176,108 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Resident-weight forward projection: for K <= 128 and Nc <= 64 the whole B = W stays in LDS for
+// the life of the block and every wave walks 16-row tiles on its own (no block barrier in the
+// loop): A fragments of the NEXT tile are loaded to registers before the current tile's MFMAs,
+// the C tile goes through a wave-private LDS patch so that rows leave as whole 256-byte runs, and
+// the logit halves f1/f2 are taken from that patch.  NS = ceil(K/16) k-steps of 16, NT column tiles.
+// ------------------------------------------------------------------------------------------
+constexpr int kResWaves = 8;
+
+template <int NS, int NT>
+__global__ __launch_bounds__(64 * kResWaves) void proj_resident_kernel(GemmArgs g, int64_t n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ws = smem;                                   // [NS*16][kLdB]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *Cs = smem + NS * 16 * kLdB + wave * 16 * kLdB;   // [16][kLdB], private to this wave
+    const int m = lane & 15, kq = lane >> 4;
+
+    for (int e = threadIdx.x; e < NS * 16 * 64; e += 64 * kResWaves) {
+        const int k = e >> 6, c = e & 63;
+        Ws[k * kLdB + c] = (k < g.K && c < g.Nc) ? g.B[(int64_t)k * g.sbk + c] : 0.f;
+    }
+    __syncthreads();
+
+    const int c4 = lane & 15;
+    const int col = 4 * c4;
+    float4 a1v = make_float4(0.f, 0.f, 0.f, 0.f), a2v = a1v, bv = a1v;
+    int head = 0;
+    if (col < g.Nc) {
+        if (g.f1) {
+            a1v = *reinterpret_cast<const float4 *>(g.a1 + col);
+            a2v = *reinterpret_cast<const float4 *>(g.a2 + col);
+            head = c4 / g.LPH;
+        }
+        if (g.cbias) bv = *reinterpret_cast<const float4 *>(g.cbias + col);
+    }
+    const int64_t tw = (int64_t)gridDim.x * kResWaves;
+    int64_t tile = (int64_t)blockIdx.x * kResWaves + wave;
+
+    float4 cur[NS], nxt[NS];
+    auto load_tile = [&](int64_t t, float4 (&dst)[NS]) {
+        const int64_t row = t * 16 + m;
+        const bool ok = t < n_tiles && row < g.n;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int k = 16 * s + 4 * kq;
+            dst[s] = (ok && k < g.K) ? *reinterpret_cast<const float4 *>(g.A + row * g.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_tile(tile, cur);
+    for (; tile < n_tiles; tile += tw) {
+        load_tile(tile + tw, nxt);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float av[4] = {cur[s].x, cur[s].y, cur[s].z, cur[s].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float *brow = Ws + (16 * s + 4 * kq + t) * kLdB + m;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], brow[16 * nt], acc[nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(4 * kq + r) * kLdB + 16 * nt + m] = acc[nt][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = (lane >> 4) + 4 * i;
+            const int64_t row = tile * 16 + rl;
+            float4 v = *reinterpret_cast<const float4 *>(Cs + rl * kLdB + col);
+            if (g.f1) {
+                float p1 = v.x * a1v.x + v.y * a1v.y + v.z * a1v.z + v.w * a1v.w;
+                float p2 = v.x * a2v.x + v.y * a2v.y + v.z * a2v.z + v.w * a2v.w;
+                for (int o = 1; o < g.LPH; o <<= 1) {
+                    p1 += __shfl_xor(p1, o, 64);
+                    p2 += __shfl_xor(p2, o, 64);
+                }
+                if (row < g.n && col < g.Nc && (c4 % g.LPH) == 0) {
+                    g.f1[row * g.H + head] = p1 + g.b1[head];
+                    g.f2[row * g.H + head] = p2 + g.b2[head];
+                }
+            }
+            if (row < g.n && col < g.Nc) {
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                *reinterpret_cast<float4 *>(g.C + row * g.ldc + col) = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int s = 0; s < NS; ++s) cur[s] = nxt[s];
+    }
+}
+
 // f1/f2 from finished Wh rows when hd > 64 (a row spans several column tiles).
 template <int G>
 __global__ __launch_bounds__(256) void logit_halves_kernel(const float *Wh, int64_t n, int H, int LPH,
@@ -284,14 +386,89 @@ __global__ __launch_bounds__(256) void xt_gemm_kernel(const float *X, int64_t n,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// dW = X^T . dY with whole-line loads (X rows and dY rows 16-byte aligned).  Lane (m, kq) of a wave
+// loads float4 X[node+kq][64*fs + 4m ..] and float4 dY[node+kq][y0 + 4m ..]: 16 lanes cover 256
+// contiguous bytes of one node's row.  Component j of the X vector is the A operand of tile
+// (fs, j) (feature 64*fs + 4*row + j), component c of the dY vector the B operand of tile c
+// (column y0 + 4*col + c): a fixed permutation of the output, undone when the partial is parked.
+// Block (bx, by, bz): node chunks bx, bx+gridDim.x, ...; features [128*by, +64*FS); columns [64*bz, +64).
+// ------------------------------------------------------------------------------------------
+template <int FS>
+__global__ __launch_bounds__(256, 2) void xt_gemm_lines_kernel(const float *X, int64_t n, int F, int64_t ldx,
+                                                             const float *dY, int hd, float *ws) {
+    __shared__ float red[64 * FS * 65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int f0 = blockIdx.y * 64 * FS;
+    const int y0 = blockIdx.z * 64;
+    f32x4 acc[FS][4][4];
+#pragma unroll
+    for (int fs = 0; fs < FS; ++fs)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[fs][j][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bool fok[FS];
+#pragma unroll
+    for (int fs = 0; fs < FS; ++fs) fok[fs] = f0 + 64 * fs + 4 * m < F;      // F % 4 == 0: a float4 is all in or all out
+    const bool yok = y0 + 4 * m < hd;
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t wave_stride = (int64_t)gridDim.x * 4 * kNodeChunk;
+    for (int64_t base = wave_id * kNodeChunk; base < n; base += wave_stride) {
+#pragma unroll 2
+        for (int s = 0; s < kNodeChunk / 4; ++s) {
+            const int64_t node = base + 4 * s + kq;
+            const bool nok = node < n;
+            f32x4 xa[FS];
+#pragma unroll
+            for (int fs = 0; fs < FS; ++fs)
+                xa[fs] = (nok && fok[fs]) ? *reinterpret_cast<const f32x4 *>(X + node * ldx + f0 + 64 * fs + 4 * m) : zero;
+            const f32x4 yb = (nok && yok) ? *reinterpret_cast<const f32x4 *>(dY + node * hd + y0 + 4 * m) : zero;
+#pragma unroll
+            for (int fs = 0; fs < FS; ++fs)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[fs][j][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[fs][j], yb[c], acc[fs][j][c], 0, 0, 0);
+        }
+    }
+    // fixed-order sum of the four waves; red[feature_local][column_local]
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int fs = 0; fs < FS; ++fs)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float *p = red + (64 * fs + 4 * (4 * kq + r) + j) * 65 + 4 * m + c;
+                            *p = (w == 0) ? acc[fs][j][c][r] : *p + acc[fs][j][c][r];
+                        }
+        }
+        __syncthreads();
+    }
+    // ws layout: [gridDim.x][Fp = gridDim.y*64*FS][hdp = gridDim.z*64]
+    const int Fp = gridDim.y * 64 * FS, hdp = gridDim.z * 64;
+    float *out = ws + ((int64_t)blockIdx.x * Fp + f0) * hdp + y0;
+    for (int e = threadIdx.x; e < 64 * FS * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        out[(int64_t)r * hdp + c] = red[r * 65 + c];
+    }
+}
+
 // dW[f][c] = sum_b ws[b][f][c]   (f < F, c < hd; ws rows are NT16 wide)
 __global__ void reduce_dw_kernel(const float *ws, int nblocks, int Fp, int NT16, int F, int hd, float *dW) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= F * hd) return;
-    const int f = e / hd, c = e % hd;
-    float t = 0.f;
-    for (int b = 0; b < nblocks; ++b) t += ws[((int64_t)b * Fp + f) * NT16 + c];
-    dW[e] = t;
+    const int e = blockIdx.x * kSumCols + threadIdx.x;
+    const bool ok = e < F * hd;
+    const int f = ok ? e / hd : 0, c = ok ? e % hd : 0;
+    const float t = block_column_sum(nblocks, [&](int b) { return ok ? ws[((int64_t)b * Fp + f) * NT16 + c] : 0.f; });
+    if (ok && threadIdx.y == 0) dW[e] = t;
 }
 
 // da1 = sum_i df1[i,h] Wh[i,h,:], da2 likewise with df2, db1 = sum_i df1, db2 = sum_i df2.
@@ -336,18 +513,43 @@ __global__ __launch_bounds__(256) void attn_param_grad_kernel(const float *Wh, c
 __global__ void reduce_attn_param_kernel(const float *ws, int nblocks, int hd, int H, float *da1, float *da2,
                                          float *db1, float *db2) {
     const int width = 2 * hd + 2 * H;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
-    float t = 0.f;
-    for (int b = 0; b < nblocks; ++b) t += ws[(int64_t)b * width + c];
+    const int c = blockIdx.x * kSumCols + threadIdx.x;
+    const bool ok = c < width;
+    const float t = block_column_sum(nblocks, [&](int b) { return ok ? ws[(int64_t)b * width + c] : 0.f; });
+    if (!ok || threadIdx.y != 0) return;
     if (c < hd) da1[c] = t;
     else if (c < 2 * hd) da2[c - hd] = t;
     else if (c < 2 * hd + H) db1[c - 2 * hd] = t;
     else db2[c - 2 * hd - H] = t;
 }
 
+template <int NS>
+static int launch_resident(const GemmArgs &g, hipStream_t st, const char *name) {
+    const int64_t n_tiles = (g.n + 15) / 16;
+    const unsigned nb = (unsigned)std::min<int64_t>(512, (n_tiles + kResWaves - 1) / kResWaves);
+    const size_t lds = (size_t)(NS * 16 + kResWaves * 16) * kLdB * sizeof(float);
+    if (g.Nc <= 16) hipLaunchKernelGGL((proj_resident_kernel<NS, 1>), dim3(nb), dim3(64 * kResWaves), lds, st, g, n_tiles);
+    else hipLaunchKernelGGL((proj_resident_kernel<NS, 4>), dim3(nb), dim3(64 * kResWaves), lds, st, g, n_tiles);
+    GATMI_LAUNCH_CHECK(name);
+    return GATMI_OK;
+}
+
 static int launch_tall_gemm(const GemmArgs &g, hipStream_t st, const char *name) {
     if (g.n == 0 || g.Nc == 0) return GATMI_OK;
+    const bool lines = (g.lda % 4 == 0) && (g.K % 4 == 0) && aligned16(g.A) && (g.ldc % 4 == 0) && aligned16(g.C);
+    if (lines && g.sbc == 1 && g.K <= 128 && g.Nc <= 64 && g.Nc % 4 == 0 && !g.accumulate && g.n >= 4096 &&
+        (!g.cbias || aligned16(g.cbias))) {
+        switch ((g.K + 15) / 16) {
+            case 1: return launch_resident<1>(g, st, name);
+            case 2: return launch_resident<2>(g, st, name);
+            case 3: return launch_resident<3>(g, st, name);
+            case 4: return launch_resident<4>(g, st, name);
+            case 5: return launch_resident<5>(g, st, name);
+            case 6: return launch_resident<6>(g, st, name);
+            case 7: return launch_resident<7>(g, st, name);
+            default: return launch_resident<8>(g, st, name);
+        }
+    }
     const dim3 grid((unsigned)((g.n + kTileRows - 1) / kTileRows), (unsigned)((g.Nc + kTileCols - 1) / kTileCols));
     const bool vec = (g.lda % 4 == 0) && (g.K % 4 == 0) && aligned16(g.A);
     if (vec) hipLaunchKernelGGL(tall_gemm_kernel<true>, grid, dim3(256), 0, st, g);
@@ -374,8 +576,23 @@ static int launch_attn_param_grad(const float *Wh, const float *df1, const float
     hipLaunchKernelGGL(attn_param_grad_kernel<G>, dim3(nb), dim3(256), 0, st, Wh, df1, df2, n, H, LPH, ws);
     GATMI_LAUNCH_CHECK("attn_param_grad");
     const int width = 2 * 4 * G + 2 * H;
-    hipLaunchKernelGGL(reduce_attn_param_kernel, dim3((width + 63) / 64), dim3(64), 0, st, ws, (int)nb, 4 * G, H, da1, da2, db1, db2);
+    hipLaunchKernelGGL(reduce_attn_param_kernel, dim3((width + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, ws, (int)nb, 4 * G, H, da1, da2, db1, db2);
     GATMI_LAUNCH_CHECK("reduce_attn_param");
+    return GATMI_OK;
+}
+
+static int launch_xt_lines(const float *X, int64_t n, int F, int64_t ldx, const float *dY, int hd, float *ws,
+                           float *dW, hipStream_t st) {
+    const int FS = F <= 64 ? 1 : 2;
+    const unsigned gy = (unsigned)((F + 64 * FS - 1) / (64 * FS)), gz = (unsigned)((hd + 63) / 64);
+    const unsigned gx = (unsigned)std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 4 * kNodeChunk - 1) / (4 * kNodeChunk)));
+    const dim3 grid(gx, gy, gz);
+    if (FS == 1) hipLaunchKernelGGL(xt_gemm_lines_kernel<1>, grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws);
+    else hipLaunchKernelGGL(xt_gemm_lines_kernel<2>, grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws);
+    GATMI_LAUNCH_CHECK("xt_gemm_lines");
+    hipLaunchKernelGGL(reduce_dw_kernel, dim3((F * hd + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, ws, (int)gx,
+                       (int)(gy * 64 * FS), (int)(gz * 64), F, hd, dW);
+    GATMI_LAUNCH_CHECK("reduce_dw");
     return GATMI_OK;
 }
 
@@ -392,7 +609,7 @@ static int launch_xt_gemm(const float *X, int64_t n, int F, int64_t ldx, const f
     else { nt_pad = 4; hipLaunchKernelGGL((xt_gemm_kernel<MT, 4>), grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws); }
     GATMI_LAUNCH_CHECK("xt_gemm");
     const int Fp = gy * MT * 16;
-    hipLaunchKernelGGL(reduce_dw_kernel, dim3((F * hd + 255) / 256), dim3(256), 0, st, ws, (int)gx, Fp, nt_pad * 16, F, hd, dW);
+    hipLaunchKernelGGL(reduce_dw_kernel, dim3((F * hd + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, ws, (int)gx, Fp, nt_pad * 16, F, hd, dW);
     GATMI_LAUNCH_CHECK("reduce_dw");
     return GATMI_OK;
 }
@@ -448,7 +665,9 @@ extern "C" size_t gatmi_proj_bwd_ws_floats(int32_t f_in, int32_t H, int32_t dp) 
     const int hd = H * dp;
     const int mt = dw_mt(f_in);
     const size_t fp = (size_t)((f_in + mt * 16 - 1) / (mt * 16)) * mt * 16;
-    const size_t dw = (size_t)kRedBlocks * fp * 64;
+    const size_t fs = f_in <= 64 ? 64 : 128;
+    const size_t dw_lines = (size_t)kRedBlocks * (((size_t)f_in + fs - 1) / fs * fs) * (((size_t)hd + 63) / 64 * 64);
+    const size_t dw = std::max((size_t)kRedBlocks * fp * 64, dw_lines);
     const size_t da = (size_t)kRedBlocks * (size_t)(2 * hd + 2 * H);
     return std::max(dw, da);
 }
@@ -473,6 +692,8 @@ extern "C" int gatmi_proj_bwd_params(const float *X, int64_t n, int32_t f_in, in
 #undef X_
         if (rc) return rc;
     }
+    if (ldx % 4 == 0 && f_in % 4 == 0 && aligned16(X) && aligned16(dWh) && f_in <= 1024)
+        return launch_xt_lines(X, n, f_in, ldx, dWh, hd, ws, dW, st);
     // dW in column slabs of 64 (one slab for hd <= 64)
     for (int c0 = 0; c0 < hd; c0 += 64) {
         const int w = std::min(64, hd - c0);
