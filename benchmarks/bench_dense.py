@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Secondary measurement: BASELINE.json configs[2] — batched dense small graphs (B x 264 nodes,
+8 heads x 8, 64 input features), forward + backward of one layer through DenseGATLayerFn.
+Prints one JSON line (pair-slots/s = B*N^2 / t, and the HBM fraction from the survey's
+0.96 MB/graph byte model)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--nodes", type=int, default=264)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--fwd-only", action="store_true")
+    a = ap.parse_args()
+    from gat_amd import _lib, ops, synth
+    dev = torch.device("cuda:0")
+    B, N, F, H, D = a.batch, a.nodes, 64, 8, 8
+    g = torch.Generator(device=dev).manual_seed(2)
+    adj = torch.rand(B, N, N, device=dev, generator=g) < 0.05
+    adj = adj | adj.transpose(1, 2) | torch.eye(N, dtype=torch.bool, device=dev)[None]
+    bias_mat = torch.where(adj, 0.0, -1e9).to(torch.float32)
+    del adj
+    x = synth.normal((B, N, F), 3, dev)
+    p = synth.glorot_layer(F, H, D, 7, dev)
+    for v in p.values():
+        v.requires_grad_(not a.fwd_only)
+    dout = synth.normal((B, N, H * D), 8, dev)
+    cfg = ops.make_cfg(H, D, "elu")
+
+    rec = {}
+    raw = _lib.call
+
+    def timed(name, *args):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); raw(name, *args); e1.record()
+        rec.setdefault(name, []).append((e0, e1))
+
+    def step():
+        for v in p.values():
+            v.grad = None
+        out = ops.dense_gat_layer(x, p["W"], p["a1"], p["a2"], p["b1"], p["b2"], p["bias"], bias_mat, cfg)
+        if not a.fwd_only:
+            out.backward(dout)
+    for _ in range(a.warmup):
+        step()
+    _lib.call = timed
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / a.steps * 1e3
+    _lib.call = raw
+    alg = B * (2 * N * N * 4 + 2 * N * F * 4 + 4 * N * H * D * 4)
+    print(json.dumps({"workload": "dense batched graphs B=%d N=%d F=%d %dx%d %s" % (B, N, F, H, D, "fwd" if a.fwd_only else "fwd+bwd"),
+                      "ms_per_step": round(ms, 4), "pair_slots_per_s": B * N * N / (ms * 1e-3),
+                      "hbm_frac_survey_model": round(alg / (ms * 1e-3) / 8e12, 4),
+                      "kernels_ms": {k: round(sum(x0.elapsed_time(x1) for x0, x1 in v) / len(v), 4) for k, v in sorted(rec.items())}}))
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,8 @@ CASES = [
     (1, 130, 20, 4, 16, "elu", False),
     (2, 33, 6, 1, 64, "identity", False),
     (4, 19, 5, 2, 4, "elu", True),
+    (1, 1000, 10, 8, 8, "elu", False),      # too large for the LDS-resident kernels: chunked path
+    (1, 530, 8, 1, 64, "identity", False),  # same for a single wide head
 ]
 
 
