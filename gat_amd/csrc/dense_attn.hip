@@ -34,8 +34,15 @@ struct DenseFwdArgs {
     const float *Wh, *f1, *f2, *bias_mat, *bias, *resid;
     float *out, *agg, *pos, *lse, *q;
     int activation;
-    float slope;
+    float slope, coef_keep, feat_keep;
+    uint64_t seed;
 };
+
+// coefficient-dropout factor of entry (i, j) of graph b, head hg: 0 or 1/keep (utils/layers.py:20)
+__device__ __forceinline__ float coef_drop_scale(uint64_t seed, int64_t b, int N, int H, int i, int j, int hg, float keep) {
+    const uint64_t idx = (((uint64_t)b * N + (uint64_t)i) * N + (uint64_t)j) * H + hg;
+    return keep_mask(seed, idx, keep) ? 1.0f / keep : 0.f;
+}
 
 // How the four waves of a block split the work: heads first (each wave keeps only HPW heads'
 // accumulators, so registers stay low and many blocks fit a CU), 16-row tiles with what is left.
@@ -56,7 +63,7 @@ __device__ __forceinline__ void load_mask4(const float *bm, int j, int N, bool v
     }
 }
 
-template <int H, int DP, bool SAVE>
+template <int H, int DP, bool SAVE, bool DROP>
 __global__ __launch_bounds__(256) void dense_attn_fwd_kernel(DenseFwdArgs a) {
     using S = WaveSplit<H>;
     constexpr int HPW = S::HPW;
@@ -114,12 +121,18 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_kernel(DenseFwdArgs a) {
             acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if constexpr (SAVE) accp[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+    float ssum[HPW], qsum[HPW];            // dropout only: denominators from the UNdropped numerators
+#pragma unroll
+    for (int h = 0; h < HPW; ++h) ssum[h] = qsum[h] = 0.f;
     for (int jc = 0; jc < N; jc += kJC) {
         __syncthreads();
         for (int e = threadIdx.x; e < kJC * (HD / 4); e += 256) {
             const int r = e / (HD / 4), c = e % (HD / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (jc + r < N) v = *reinterpret_cast<const float4 *>(a.Wh + (b * N + jc + r) * (int64_t)HD + 4 * c);
+            if constexpr (DROP) {
+                if (a.feat_keep < 1.f) v = drop_feat(v, a.seed, b * N + jc + r, HD, 4 * c, a.feat_keep);
+            }
             *reinterpret_cast<float4 *>(vs + r * LD + 4 * c) = v;
         }
         for (int e = threadIdx.x; e < kJC * H; e += 256) f2s[e] = (jc + e / H < N) ? f2b[(int64_t)jc * H + e] : 0.f;
@@ -135,7 +148,13 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_kernel(DenseFwdArgs a) {
 #pragma unroll
                 for (int h = 0; h < HPW; ++h) {
                     const float z = f1v[h] + f2s[(jl + 4 * kq + t) * H + h0 + h];
-                    const float p = exp_neg(leaky(z, a.slope) + bv[t] - mx[h]);   // 0 for j >= N (mask -inf)
+                    const float p0 = exp_neg(leaky(z, a.slope) + bv[t] - mx[h]);   // 0 for j >= N (mask -inf)
+                    float p = p0;
+                    if constexpr (DROP) {
+                        ssum[h] += p0;
+                        qsum[h] += z > 0.f ? p0 : 0.f;
+                        if (a.coef_keep < 1.f) p = p0 * coef_drop_scale(a.seed, b, N, H, irow, min(jc + jl + 4 * kq + t, N - 1), h0 + h, a.coef_keep);
+                    }
                     const float pp = z > 0.f ? p : 0.f;
 #pragma unroll
                     for (int nt = 0; nt < NTH; ++nt) {
@@ -149,6 +168,13 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_kernel(DenseFwdArgs a) {
         }
     }
     if (i0 >= N) return;
+    if constexpr (DROP) {
+#pragma unroll
+        for (int h = 0; h < HPW; ++h) {
+            ssum[h] += __shfl_xor(ssum[h], 16, 64); ssum[h] += __shfl_xor(ssum[h], 32, 64);
+            qsum[h] += __shfl_xor(qsum[h], 16, 64); qsum[h] += __shfl_xor(qsum[h], 32, 64);
+        }
+    }
     // ---- epilogue: C layout, lane (kq, c = m) holds rows 4*kq + r, column c of each tile --------
     constexpr int NT_ONES = DP / 16, C_ONES = DP % 16;   // tile / column of the ones column
 #pragma unroll
@@ -157,11 +183,11 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_kernel(DenseFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = i0 + 4 * kq + r;
-            const float s = __shfl(acc[h][NT_ONES][r], (lane & 48) | C_ONES, 64);
+            const float s = DROP ? __shfl(ssum[h], 4 * kq + r, 64) : __shfl(acc[h][NT_ONES][r], (lane & 48) | C_ONES, 64);
             const float mrow = __shfl(mx[h], 4 * kq + r, 64);
             const float inv = s > 0.f ? 1.0f / s : 0.f;
             float qv = 0.f;
-            if constexpr (SAVE) qv = __shfl(accp[h][NT_ONES][r], (lane & 48) | C_ONES, 64) * inv;
+            if constexpr (SAVE) qv = (DROP ? __shfl(qsum[h], 4 * kq + r, 64) : __shfl(accp[h][NT_ONES][r], (lane & 48) | C_ONES, 64)) * inv;
             if (i < N) {
                 const int64_t node = b * N + i;
                 if constexpr (SAVE) {
@@ -197,11 +223,12 @@ struct DenseBwdArgs {
     int N;
     const float *g, *stats, *Wh, *f2, *bias_mat, *df1, *a1, *a2;
     float *dWh, *df2;
-    float slope;
+    float slope, coef_keep, feat_keep;
+    uint64_t seed;
 };
 
 // Block (b, source tiles): a wave owns 16 sources x HPW heads and walks all destination tiles.
-template <int H, int DP>
+template <int H, int DP, bool DROP>
 __global__ __launch_bounds__(256) void dense_attn_bwd_kernel(DenseBwdArgs a) {
     using S = WaveSplit<H>;
     constexpr int HPW = S::HPW;
@@ -227,7 +254,12 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_kernel(DenseBwdArgs a) {
         f2v[h] = a.f2[(b * N + jcol) * H + h0 + h];
         df2[h] = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) whb[h][s] = a.Wh[(b * N + jcol) * (int64_t)HD + (h0 + h) * DP + 4 * s + kq];
+        for (int s = 0; s < KS; ++s) {
+            whb[h][s] = a.Wh[(b * N + jcol) * (int64_t)HD + (h0 + h) * DP + 4 * s + kq];
+            if constexpr (DROP) {
+                if (a.feat_keep < 1.f) whb[h][s] = drop_feat1(whb[h][s], a.seed, b * N + jcol, HD, (h0 + h) * DP + 4 * s + kq, a.feat_keep);
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < NTH; ++nt) acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -267,8 +299,12 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_kernel(DenseBwdArgs a) {
                     const float *st = ss + (il + 4 * kq + r) * 3 * H;
                     const float z = st[hg] + f2v[h];
                     const float alpha = exp_neg(leaky(z, a.slope) + bv[r] - st[H + hg]);   // 0 outside the graph
-                    al[r] = alpha;
-                    df2[h] += alpha * (da[r] - st[2 * H + hg]) * (z > 0.f ? 1.f : a.slope);
+                    float mk = 1.f;
+                    if constexpr (DROP) {
+                        if (a.coef_keep < 1.f) mk = coef_drop_scale(a.seed, b, N, H, min(ic + il + 4 * kq + r, N - 1), jcol, hg, a.coef_keep);
+                    }
+                    al[r] = alpha * mk;
+                    df2[h] += alpha * (da[r] * mk - st[2 * H + hg]) * (z > 0.f ? 1.f : a.slope);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -302,6 +338,9 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_kernel(DenseBwdArgs a) {
                 const int c = 16 * nt + m;
                 if (c < DP) {
                     float v = acc[h][nt][r];
+                    if constexpr (DROP) {
+                        if (a.feat_keep < 1.f) v = drop_feat1(v, a.seed, b * N + j, HD, hg * DP + c, a.feat_keep);
+                    }
                     if (a.a1) v += d1 * a.a1[hg * DP + c] + d2 * a.a2[hg * DP + c];
                     a.dWh[(b * N + j) * (int64_t)HD + hg * DP + c] = v;
                 }
@@ -331,7 +370,7 @@ __device__ __forceinline__ void graph_and_head_group(int WH, int64_t &graph, int
 constexpr int kMaskBatch = 6;      // 16-source steps whose mask loads are issued together (forward)
 constexpr int kMaskBatchBwd = 1;   // 16-destination steps whose mask loads are issued together (backward)
 
-template <int H, int DP, bool SAVE>
+template <int H, int DP, bool SAVE, bool DROP>
 __global__ __launch_bounds__(256) void dense_attn_fwd_hg_kernel(DenseFwdArgs a) {
     using S = WaveSplit<H>;
     constexpr int HPW = S::HPW;
@@ -354,6 +393,9 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_hg_kernel(DenseFwdArgs a) 
         const int r = e / (W / 4), c = e % (W / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < N) v = *reinterpret_cast<const float4 *>(a.Wh + (b * N + r) * (int64_t)HD + h0 * DP + 4 * c);
+        if constexpr (DROP) {
+            if (a.feat_keep < 1.f) v = drop_feat(v, a.seed, b * N + r, HD, h0 * DP + 4 * c, a.feat_keep);
+        }
         *reinterpret_cast<float4 *>(vs + r * LDV + 4 * c) = v;
     }
     for (int e = threadIdx.x; e < Np * HPW; e += 256) {
@@ -410,6 +452,9 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_hg_kernel(DenseFwdArgs a) 
                 acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if constexpr (SAVE) accp[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+        float ssum[HPW], qsum[HPW];        // dropout only: denominators from the UNdropped numerators
+#pragma unroll
+        for (int h = 0; h < HPW; ++h) ssum[h] = qsum[h] = 0.f;
         for (int jg = 0; jg < Np; jg += 16 * kMaskBatch) {         // sweep 2: numerators -> matrix pipe
           float bvv[kMaskBatch][4];
 #pragma unroll
@@ -435,7 +480,13 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_hg_kernel(DenseFwdArgs a) 
 #pragma unroll
                 for (int h = 0; h < HPW; ++h) {
                     const float z = f1v[h] + f2r[t][h];
-                    const float p = exp_neg(leaky(z, a.slope) + bv[t] - mx[h]);   // 0 for j >= N (mask -inf)
+                    const float p0 = exp_neg(leaky(z, a.slope) + bv[t] - mx[h]);   // 0 for j >= N (mask -inf)
+                    float p = p0;
+                    if constexpr (DROP) {
+                        ssum[h] += p0;
+                        qsum[h] += z > 0.f ? p0 : 0.f;
+                        if (a.coef_keep < 1.f) p = p0 * coef_drop_scale(a.seed, b, N, H, irow, min(j0 + 4 * kq + t, N - 1), h0 + h, a.coef_keep);
+                    }
                     const float pp = z > 0.f ? p : 0.f;
 #pragma unroll
                     for (int nt = 0; nt < NTH; ++nt) {
@@ -445,17 +496,24 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_hg_kernel(DenseFwdArgs a) 
                 }
           }
         }
+        if constexpr (DROP) {
+#pragma unroll
+            for (int h = 0; h < HPW; ++h) {
+                ssum[h] += __shfl_xor(ssum[h], 16, 64); ssum[h] += __shfl_xor(ssum[h], 32, 64);
+                qsum[h] += __shfl_xor(qsum[h], 16, 64); qsum[h] += __shfl_xor(qsum[h], 32, 64);
+            }
+        }
 #pragma unroll
         for (int h = 0; h < HPW; ++h) {
             const int hg = h0 + h;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + 4 * kq + r;
-                const float s = __shfl(acc[h][NT_ONES][r], (lane & 48) | C_ONES, 64);
+                const float s = DROP ? __shfl(ssum[h], 4 * kq + r, 64) : __shfl(acc[h][NT_ONES][r], (lane & 48) | C_ONES, 64);
                 const float mrow = __shfl(mx[h], 4 * kq + r, 64);
                 const float inv = s > 0.f ? 1.0f / s : 0.f;
                 float qv = 0.f;
-                if constexpr (SAVE) qv = __shfl(accp[h][NT_ONES][r], (lane & 48) | C_ONES, 64) * inv;
+                if constexpr (SAVE) qv = (DROP ? __shfl(qsum[h], 4 * kq + r, 64) : __shfl(accp[h][NT_ONES][r], (lane & 48) | C_ONES, 64)) * inv;
                 if (i < N) {
                     const int64_t node = b * N + i;
                     if constexpr (SAVE) {
@@ -487,7 +545,7 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_hg_kernel(DenseFwdArgs a) 
     }
 }
 
-template <int H, int DP>
+template <int H, int DP, bool DROP>
 __global__ __launch_bounds__(256) void dense_attn_bwd_hg_kernel(DenseBwdArgs a) {
     using S = WaveSplit<H>;
     constexpr int HPW = S::HPW;
@@ -537,7 +595,12 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_hg_kernel(DenseBwdArgs a) 
             f2v[h] = a.f2[(b * N + jcol) * H + h0 + h];
             df2[h] = 0.f;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) whb[h][s] = a.Wh[(b * N + jcol) * (int64_t)HD + (h0 + h) * DP + 4 * s + kq];
+            for (int s = 0; s < KS; ++s) {
+            whb[h][s] = a.Wh[(b * N + jcol) * (int64_t)HD + (h0 + h) * DP + 4 * s + kq];
+            if constexpr (DROP) {
+                if (a.feat_keep < 1.f) whb[h][s] = drop_feat1(whb[h][s], a.seed, b * N + jcol, HD, (h0 + h) * DP + 4 * s + kq, a.feat_keep);
+            }
+        }
 #pragma unroll
             for (int nt = 0; nt < NTH; ++nt) acc[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -576,8 +639,12 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_hg_kernel(DenseBwdArgs a) 
                 for (int r = 0; r < 4; ++r) {
                     const float z = st[r].x + f2v[h];
                     const float alpha = exp_neg(leaky(z, a.slope) + bv[r] - st[r].y);   // 0 outside the graph
-                    al[r] = alpha;
-                    df2[h] += alpha * (da[r] - st[r].z) * (z > 0.f ? 1.f : a.slope);
+                    float mk = 1.f;
+                    if constexpr (DROP) {
+                        if (a.coef_keep < 1.f) mk = coef_drop_scale(a.seed, b, N, H, min(il + 4 * kq + r, N - 1), jcol, h0 + h, a.coef_keep);
+                    }
+                    al[r] = alpha * mk;
+                    df2[h] += alpha * (da[r] * mk - st[r].z) * (z > 0.f ? 1.f : a.slope);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -605,6 +672,9 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_hg_kernel(DenseBwdArgs a) 
                     const int c = 16 * nt + m;
                     if (c < DP) {
                         float v = acc[h][nt][r];
+                    if constexpr (DROP) {
+                        if (a.feat_keep < 1.f) v = drop_feat1(v, a.seed, b * N + j, HD, hg * DP + c, a.feat_keep);
+                    }
                         if (a.a1) v += d1 * a.a1[hg * DP + c] + d2 * a.a2[hg * DP + c];
                         a.dWh[(b * N + j) * (int64_t)HD + hg * DP + c] = v;
                     }
@@ -642,6 +712,7 @@ using namespace gatmi;
 extern "C" int gatmi_dense_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t dp,
                                     const float *Wh, const float *f1, const float *f2, const float *bias_mat,
                                     const float *bias, const float *resid, int32_t activation, float slope,
+                                    float coef_keep, float feat_keep, uint64_t seed,
                                     float *out, float *agg, float *pos, float *lse, float *q, void *stream) {
     int G, LPH;
     int rc = check_shape(H, dp, &G, &LPH);
@@ -653,20 +724,25 @@ extern "C" int gatmi_dense_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t dp,
     GATMI_REQUIRE(activation == GATMI_ACT_IDENTITY || activation == GATMI_ACT_ELU, GATMI_EUNSUPPORTED, "dense_attn_fwd: activation %d", activation);
     const bool save = agg || pos || lse || q;
     GATMI_REQUIRE(!save || (agg && pos && lse && q), GATMI_EINVAL, "dense_attn_fwd: agg, pos, lse, q must be given together");
+    GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "dense_attn_fwd: keep probabilities must be in (0,1]");
+    const bool drop = coef_keep < 1.f || feat_keep < 1.f;
+    GATMI_REQUIRE(!drop || save, GATMI_EINVAL, "dense_attn_fwd: dropout is a training-time option and needs agg, pos, lse, q");
     GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(bias_mat);
     DenseFwdArgs a;
     a.B = B; a.N = N; a.Wh = Wh; a.f1 = f1; a.f2 = f2; a.bias_mat = bias_mat; a.bias = bias; a.resid = resid;
-    a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.activation = activation; a.slope = slope;
+    a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.activation = activation; a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X(hh, dd)                                                                                             \
     if (H == hh && dp == dd) {                                                                                \
         const dim3 grid = dense_grid<hh>(B, N);                                                               \
         const size_t lds = fwd_hg_lds<hh, dd>(N);                                                             \
         const dim3 hgrid((unsigned)(((B + 7) / 8) * 8 * WaveSplit<hh>::WH));                                           \
-        if (lds <= kSmallGraphLds && save) hipLaunchKernelGGL((dense_attn_fwd_hg_kernel<hh, dd, true>), hgrid, dim3(256), lds, st, a);  \
-        else if (lds <= kSmallGraphLds) hipLaunchKernelGGL((dense_attn_fwd_hg_kernel<hh, dd, false>), hgrid, dim3(256), lds, st, a);    \
-        else if (save) hipLaunchKernelGGL((dense_attn_fwd_kernel<hh, dd, true>), grid, dim3(256), 0, st, a);        \
-        else hipLaunchKernelGGL((dense_attn_fwd_kernel<hh, dd, false>), grid, dim3(256), 0, st, a);            \
+        if (lds <= kSmallGraphLds && drop) hipLaunchKernelGGL((dense_attn_fwd_hg_kernel<hh, dd, true, true>), hgrid, dim3(256), lds, st, a);  \
+        else if (lds <= kSmallGraphLds && save) hipLaunchKernelGGL((dense_attn_fwd_hg_kernel<hh, dd, true, false>), hgrid, dim3(256), lds, st, a);  \
+        else if (lds <= kSmallGraphLds) hipLaunchKernelGGL((dense_attn_fwd_hg_kernel<hh, dd, false, false>), hgrid, dim3(256), lds, st, a);    \
+        else if (drop) hipLaunchKernelGGL((dense_attn_fwd_kernel<hh, dd, true, true>), grid, dim3(256), 0, st, a);   \
+        else if (save) hipLaunchKernelGGL((dense_attn_fwd_kernel<hh, dd, true, false>), grid, dim3(256), 0, st, a);  \
+        else hipLaunchKernelGGL((dense_attn_fwd_kernel<hh, dd, false, false>), grid, dim3(256), 0, st, a);            \
         GATMI_LAUNCH_CHECK("dense_attn_fwd");                                                                 \
         return GATMI_OK;                                                                                      \
     }
@@ -678,7 +754,8 @@ extern "C" int gatmi_dense_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t dp,
 extern "C" int gatmi_dense_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t dp,
                                     const float *g, const float *stats, const float *Wh, const float *f2,
                                     const float *bias_mat, const float *df1, const float *a1, const float *a2,
-                                    float slope, float *dWh, float *df2, void *stream) {
+                                    float slope, float coef_keep, float feat_keep, uint64_t seed,
+                                    float *dWh, float *df2, void *stream) {
     int G, LPH;
     int rc = check_shape(H, dp, &G, &LPH);
     if (rc) return rc;
@@ -688,7 +765,10 @@ extern "C" int gatmi_dense_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t dp,
     GATMI_REQUIRE(g && stats && Wh && f2 && bias_mat && dWh && df2, GATMI_EINVAL, "dense_attn_bwd: null pointer");
     GATMI_REQUIRE((a1 == nullptr) == (a2 == nullptr) && (!a1 || df1), GATMI_EINVAL, "dense_attn_bwd: a1, a2 and df1 go together");
     GATMI_REQUIRE_ALIGNED(g);
+    GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "dense_attn_bwd: keep probabilities must be in (0,1]");
+    const bool drop = coef_keep < 1.f || feat_keep < 1.f;
     DenseBwdArgs a;
+    a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
     a.df1 = df1; a.a1 = a1; a.a2 = a2;
     a.B = B; a.N = N; a.g = g; a.stats = stats; a.Wh = Wh; a.f2 = f2; a.bias_mat = bias_mat; a.dWh = dWh; a.df2 = df2; a.slope = slope;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -697,8 +777,10 @@ extern "C" int gatmi_dense_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t dp,
         const dim3 grid = dense_grid<hh>(B, N);                                                   \
         const size_t lds = bwd_hg_lds<hh, dd>(N);                                                 \
         const dim3 hgrid((unsigned)(((B + 7) / 8) * 8 * WaveSplit<hh>::WH));                               \
-        if (lds <= kSmallGraphLds) hipLaunchKernelGGL((dense_attn_bwd_hg_kernel<hh, dd>), hgrid, dim3(256), lds, st, a);  \
-        else hipLaunchKernelGGL((dense_attn_bwd_kernel<hh, dd>), grid, dim3(256), 0, st, a);            \
+        if (lds <= kSmallGraphLds && drop) hipLaunchKernelGGL((dense_attn_bwd_hg_kernel<hh, dd, true>), hgrid, dim3(256), lds, st, a);  \
+        else if (lds <= kSmallGraphLds) hipLaunchKernelGGL((dense_attn_bwd_hg_kernel<hh, dd, false>), hgrid, dim3(256), lds, st, a);  \
+        else if (drop) hipLaunchKernelGGL((dense_attn_bwd_kernel<hh, dd, true>), grid, dim3(256), 0, st, a);  \
+        else hipLaunchKernelGGL((dense_attn_bwd_kernel<hh, dd, false>), grid, dim3(256), 0, st, a);            \
         GATMI_LAUNCH_CHECK("dense_attn_bwd");                                                     \
         return GATMI_OK;                                                                          \
     }

@@ -33,6 +33,24 @@ __device__ __forceinline__ bool keep_mask(uint64_t seed, uint64_t idx, float kee
     return (float)r * (1.0f / 16777216.0f) < keep_prob;
 }
 
+constexpr uint64_t kFeatSeedSalt = 0x5DEECE66Dull;
+
+// feature-dropout of one float4 of row j (columns c0..c0+3): utils/layers.py:22
+__device__ __forceinline__ float4 drop_feat(float4 v, uint64_t seed, int64_t j, int hd, int c0, float keep) {
+    const uint64_t base = (uint64_t)j * (uint64_t)hd + (uint64_t)c0;
+    const float inv = 1.0f / keep;
+    v.x = keep_mask(seed ^ kFeatSeedSalt, base + 0, keep) ? v.x * inv : 0.f;
+    v.y = keep_mask(seed ^ kFeatSeedSalt, base + 1, keep) ? v.y * inv : 0.f;
+    v.z = keep_mask(seed ^ kFeatSeedSalt, base + 2, keep) ? v.z * inv : 0.f;
+    v.w = keep_mask(seed ^ kFeatSeedSalt, base + 3, keep) ? v.w * inv : 0.f;
+    return v;
+}
+
+// one element of the same mask (row j, column c)
+__device__ __forceinline__ float drop_feat1(float v, uint64_t seed, int64_t j, int hd, int c, float keep) {
+    return keep_mask(seed ^ kFeatSeedSalt, (uint64_t)j * (uint64_t)hd + (uint64_t)c, keep) ? v / keep : 0.f;
+}
+
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
 
 // derivative of ELU written in terms of its OUTPUT y: 1 for y > 0, y + 1 (= exp(x)) otherwise

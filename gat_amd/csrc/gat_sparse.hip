@@ -47,19 +47,6 @@ __device__ __forceinline__ float4 f4_scale(float a, float4 x) { return make_floa
 __device__ __forceinline__ float4 f4_add(float4 x, float4 y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); }
 __device__ __forceinline__ float dot4(float4 x, float4 y) { return fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, x.w * y.w))); }
 
-constexpr uint64_t kFeatSeedSalt = 0x5DEECE66Dull;
-
-// feature-dropout of one float4 of row j (columns c0..c0+3): utils/layers.py:22
-__device__ __forceinline__ float4 drop_feat(float4 v, uint64_t seed, int64_t j, int hd, int c0, float keep) {
-    const uint64_t base = (uint64_t)j * (uint64_t)hd + (uint64_t)c0;
-    const float inv = 1.0f / keep;
-    v.x = keep_mask(seed ^ kFeatSeedSalt, base + 0, keep) ? v.x * inv : 0.f;
-    v.y = keep_mask(seed ^ kFeatSeedSalt, base + 1, keep) ? v.y * inv : 0.f;
-    v.z = keep_mask(seed ^ kFeatSeedSalt, base + 2, keep) ? v.z * inv : 0.f;
-    v.w = keep_mask(seed ^ kFeatSeedSalt, base + 3, keep) ? v.w * inv : 0.f;
-    return v;
-}
-
 struct RowState {
     float m, s, q;
     float4 acc, pos;

@@ -188,8 +188,6 @@ class DenseGATLayerFn(torch.autograd.Function):
         _require_cuda(x, W, bias_mat)
         if cfg.reduce != "concat":
             raise ValueError("dense layer: heads are concatenated by the kernel; average outside")
-        if cfg.coef_keep < 1.0 or cfg.feat_keep < 1.0:
-            raise NotImplementedError("dense layer: in-kernel dropout is only built for the CSR path")
         x = _f32(x).contiguous()
         B, N, F = x.shape
         bias_mat = _f32(bias_mat).contiguous()
@@ -202,13 +200,15 @@ class DenseGATLayerFn(torch.autograd.Function):
         Wp, a1p, a2p, Wrp, Wh, f1, f2, res = _project(x2, W, a1, a2, b1, b2, cfg, W_res, b_res)
         biasp = None if bias is None else _pad_last(bias.reshape(H, D), D, dp).reshape(hd)
         need_grad = any(ctx.needs_input_grad)
+        dropping = cfg.coef_keep < 1.0 or cfg.feat_keep < 1.0        # the dropout kernels write the saved tensors
         out = _new((B * N, hd), x)
         agg = pos = lse = q = None
-        if need_grad:
+        if need_grad or dropping:
             agg, pos = _new((B * N, hd), x), _new((B * N, hd), x)
             lse, q = _new((B * N, H), x), _new((B * N, H), x)
         _lib.call("gatmi_dense_attn_fwd", B, N, H, dp, ptr(Wh), ptr(f1), ptr(f2), ptr(bias_mat), ptr(biasp), ptr(res),
-                  _ACT[cfg.activation], cfg.slope, ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), st)
+                  _ACT[cfg.activation], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
+                  ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), st)
         if need_grad:
             ctx.cfg, ctx.dims = cfg, (B, N)
             ctx.has_bias, ctx.has_res = bias is not None, W_res is not None
@@ -236,7 +236,7 @@ class DenseGATLayerFn(torch.autograd.Function):
         dWh = _new((n, hd), x2)
         df2 = _new((n, H), x2)
         _lib.call("gatmi_dense_attn_bwd", B, N, H, dp, ptr(g), ptr(stats), ptr(Wh), ptr(f2), ptr(bias_mat),
-                  ptr(df1), ptr(a1p), ptr(a2p), cfg.slope, ptr(dWh), ptr(df2), st)
+                  ptr(df1), ptr(a1p), ptr(a2p), cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dWh), ptr(df2), st)
         dx, dW, da1, da2, db1, db2, dWr = _project_backward(x2, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
         if dx is not None:
             dx = dx.reshape(B, N, -1)

@@ -192,10 +192,13 @@ int gatmi_gat_bwd_finalize(int64_t n, int32_t H, int32_t dp, const float *df1, c
  * [B, N, *] tensors with the additive bias_mat [B, N, N] of utils/process.py:14-25 (any additive
  * values, not only 0 / -1e9).
  *   Wh [B,N,hd], f1,f2 [B,N,H], bias [hd] or NULL, resid [B,N,hd] or NULL; out [B,N,hd];
- *   agg, pos [B,N,hd], lse, q [B,N,H]: saved for backward (meaning as in gatmi_gat_fwd), or all NULL. */
+ *   agg, pos [B,N,hd], lse, q [B,N,H]: saved for backward (meaning as in gatmi_gat_fwd), or all NULL.
+ *   coef_keep / feat_keep / seed: dropout of layers.py:20,22 as in gatmi_gat_fwd; the masks are keyed
+ *   on (graph, i, j, head) and (graph, j, column); dropout needs the saved tensors (training). */
 int gatmi_dense_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t dp,
                          const float *Wh, const float *f1, const float *f2, const float *bias_mat,
                          const float *bias, const float *resid, int32_t activation, float slope,
+                         float coef_keep, float feat_keep, uint64_t seed,
                          float *out, float *agg, float *pos, float *lse, float *q, void *stream);
 
 /* Backward of the above, per-source part.  g, stats and df1 come from gatmi_gat_bwd_node run on
@@ -204,7 +207,8 @@ int gatmi_dense_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t dp,
 int gatmi_dense_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t dp,
                          const float *g, const float *stats, const float *Wh, const float *f2,
                          const float *bias_mat, const float *df1, const float *a1, const float *a2,
-                         float slope, float *dWh, float *df2, void *stream);
+                         float slope, float coef_keep, float feat_keep, uint64_t seed,
+                         float *dWh, float *df2, void *stream);
 
 /* Halo exchange helpers (row-partitioned multi-GPU).  pack: dst[k, :] = src[idx[k], :] for
  * k < n_idx, rows of `width` floats (send buffer of Wh / f2 rows requested by a peer); rows are

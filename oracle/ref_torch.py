@@ -57,8 +57,10 @@ def layer_csr(x, p, rowptr, col, activation="elu", reduce="concat", residual=Fal
     return out.mean(1)
 
 
-def layer_dense(x, p, bias_mat, activation="elu", reduce="concat", residual=False):
-    """Dense twin on [B,N,F] with additive [B,N,N] mask (layers.py:6-34, gat.py:11-15,25-29)."""
+def layer_dense(x, p, bias_mat, activation="elu", reduce="concat", residual=False,
+                coef_mask=None, ft_mask=None, coef_keep=1.0, ft_keep=1.0):
+    """Dense twin on [B,N,F] with additive [B,N,N] mask (layers.py:6-34, gat.py:11-15,25-29).
+    coef_mask [B,H,N,N] and ft_mask [B,N,H,D] are explicit 0/1 dropout masks (layers.py:20,22)."""
     B, n, Fin = x.shape
     H, D = p["a1"].shape
     wh = (x @ p["W"].reshape(Fin, H * D)).reshape(B, n, H, D)
@@ -66,7 +68,10 @@ def layer_dense(x, p, bias_mat, activation="elu", reduce="concat", residual=Fals
     f2 = (wh * p["a2"]).sum(-1) + p["b2"]
     logits = f1.permute(0, 2, 1)[:, :, :, None] + f2.permute(0, 2, 1)[:, :, None, :]   # [B,H,N(i),N(j)]
     coefs = torch.softmax(F.leaky_relu(logits, LEAKY_SLOPE) + bias_mat[:, None], dim=-1)
-    vals = torch.einsum("bhij,bjhd->bihd", coefs, wh)
+    if coef_mask is not None:
+        coefs = coefs * coef_mask / coef_keep
+    src_fts = wh if ft_mask is None else wh * ft_mask / ft_keep
+    vals = torch.einsum("bhij,bjhd->bihd", coefs, src_fts)
     ret = vals + p["bias"]
     if residual and Fin != D:
         ret = ret + (x @ p["W_res"].reshape(Fin, H * D)).reshape(B, n, H, D) + p["b_res"]

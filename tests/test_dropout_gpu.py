@@ -87,3 +87,46 @@ def test_rate_zero_and_eval_are_exact_identities():
     assert not torch.equal(base, dropped)
     assert torch.equal(dropped, run(ops.make_cfg(H, D, "elu", coef_drop=0.6, in_drop=0.6, training=True, seed=5)))
     assert not torch.equal(dropped, run(ops.make_cfg(H, D, "elu", coef_drop=0.6, in_drop=0.6, training=True, seed=6)))
+
+
+@pytest.mark.parametrize("B,N,H,D,coef_drop,in_drop", [(2, 60, 8, 8, 0.6, 0.6), (1, 700, 8, 8, 0.5, 0.3), (3, 33, 1, 7, 0.4, 0.0)])
+def test_dense_layer_masks_replay(B, N, H, D, coef_drop, in_drop):
+    """Same check for the dense kernels (both the LDS-resident and the chunked variants): masks are
+    keyed on (graph, i, j, head) and (graph, j, padded column)."""
+    from gat_amd import ops
+    dev = torch.device("cuda:0")
+    F = 12
+    dp = ops.padded_width(D)
+    rng = np.random.default_rng(N)
+    adj = (rng.random((B, N, N)) < 0.1) | np.eye(N, dtype=bool)[None]
+    bm = np.where(adj, 0.0, -1e9)
+    p = layer_params(F, H, D, seed=2)
+    x = rng.normal(0, 1, (B, N, F))
+    seed = 987654321
+    tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+    xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
+    cfg = ops.make_cfg(H, D, "elu", "concat", coef_drop=coef_drop, in_drop=in_drop, training=True, seed=seed)
+    out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"],
+                              torch.tensor(bm, dtype=torch.float32, device=dev), cfg)
+    dout = rng.normal(0, 1, tuple(out.shape))
+    out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
+    coef_mask = ft_mask = None
+    if coef_drop > 0:
+        b, i, j, h = np.meshgrid(np.arange(B), np.arange(N), np.arange(N), np.arange(H), indexing="ij")
+        idx = (((b * N + i) * N + j) * H + h).astype(np.uint64)
+        coef_mask = keep_mask_host(seed, idx, 1.0 - coef_drop).astype(np.float64).transpose(0, 3, 1, 2)   # [B,H,N,N]
+    if in_drop > 0:
+        cols = (np.arange(H)[:, None] * dp + np.arange(D)[None, :]).astype(np.uint64)
+        idx = np.arange(B * N, dtype=np.uint64)[:, None, None] * np.uint64(H * dp) + cols[None]
+        ft_mask = keep_mask_host(seed ^ FEAT_SALT, idx, 1.0 - in_drop).astype(np.float64).reshape(B, N, H, D)
+    rp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = ref_torch.layer_dense(rx, rp, torch.tensor(bm), "elu", "concat",
+                                coef_mask=None if coef_mask is None else torch.tensor(coef_mask),
+                                ft_mask=None if ft_mask is None else torch.tensor(ft_mask),
+                                coef_keep=1.0 - coef_drop, ft_keep=1.0 - in_drop)
+    ref.backward(torch.tensor(dout))
+    assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), what="dense forward with dropout")
+    assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what="dense dX")
+    for k in ("W", "a1", "a2", "bias"):
+        assert_close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), atol_scale=5e-6, what="dense d" + k)
