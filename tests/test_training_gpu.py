@@ -1,0 +1,18 @@
+"""End-to-end check of the training step the reference's Cora driver performs (masked softmax
+cross-entropy + L2 + Adam over SpGAT.inference, models/base_gattn.py:75-88,140-165): the loop must
+learn a planted-partition graph of Cora's shape well above chance."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cora_like_training_learns():
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import train_cora_like
+    sys.argv = ["train_cora_like.py", "--epochs", "100", "--quiet"]
+    acc = train_cora_like.main()
+    assert acc > 0.6, "test accuracy %.3f after 100 epochs (chance is 0.14)" % acc
