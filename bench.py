@@ -210,8 +210,15 @@ def main():
         if dom:
             ab = kernel_alg_bytes(dom, E_rank, n_own)
             gbps = ab / (ksum[dom][0] * 1e-3) / 1e9
+            traffic, traffic_src = None, None
+            try:   # PMC-measured HBM bytes per launch, taken in separate rocprofv3 --pmc runs of this same workload
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                if world == 1 and tj.get("workload_edges") == E_rank:
+                    traffic, traffic_src = tj["kernels"].get(dom), tj.get("source")
+            except (OSError, ValueError, KeyError):
+                pass
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                        "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "alg_bytes_per_launch": ab, "avg_ms": round(ksum[dom][0], 4)}
         lb = layer_alg_bytes(E_rank, n_own)
         lg = lb / (ms_per_step * 1e-3) / 1e9
