@@ -53,6 +53,9 @@ _SIGNATURES = {
                                      c_float, c_float, c_uint64, P, P, P, P, P, P]),
     "gatmi_dense_attn_bwd": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, P, P, c_float,
                                      c_float, c_float, c_uint64, P, P, P]),
+    "gatmi_bnf_attn_fwd": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, c_float, P, P, P, P, P, P]),
+    "gatmi_bnf_attn_bwd_ws_floats": (c_size_t, [c_int64, c_int32, c_int32]),
+    "gatmi_bnf_attn_bwd": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, P, c_float, P, P, P, P, P, P]),
     "gatmi_halo_pack": (c_int, [P, P, c_int64, c_int32, P, P]),
     "gatmi_halo_unpack_add": (c_int, [P, P, c_int64, c_int32, P, P]),
 }

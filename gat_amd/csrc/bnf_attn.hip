@@ -1,0 +1,417 @@
+// Brain-network variant of the attention step for gfx950: utils/layers.py:171-179 with the
+// coefficients of attn_v2e_BNF_V2 (:229-237).  Per graph b, head h, destination i:
+//     C_ij   = softmax_j( LeakyReLU(f1[i,h] + f2[j,h]) )              (no mask)
+//     n_ij   = m2[h] * [A_ij > 0] + A_ij                               (A = weighted adjacency)
+//     agg_i  = sum_j n_ij (m1[h] + C_ij) X_j
+//            = m1 (m2 U_i + V_i) + T2_i / s_i,   U = [A>0].X,  V = A.X,  T2 = sum_j n_ij p_ij X_j,
+// with p_ij the un-normalised softmax numerator and s_i its row sum.  All contractions over j run
+// on v_mfma_f32_16x16x4_f32 in the layout of dense_attn.hip: lane (i = l&15, kq = l>>4) computes
+// its own A-operand values for sources j0 + 4*kq + t, X tiles come from LDS as the B operand.
+//
+// Backward (per source tile, all heads in one wave): D_ij = <G_i, X_j> by MFMA (K = feature
+// width) lands in the C layout; there C, n, w = n (m1 + C) are recomputed, and w^T . G (C layout
+// reused as the A layout of the transpose) accumulates dX_j.  dA_ij = (m1 + C_ij) D_ij is written
+// per tile, df2 / dm1 / dm2 are register sums, df1 comes from the positive-part sums of the
+// forward pass (same identity as in gat_sparse.hip, with c_i = <G_i, T2_i / s_i>).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "device_common.h"
+
+namespace gatmi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBnfJC = 64;      // sources (forward) / destinations (backward) staged in LDS per step
+constexpr int kBnfBlocksMax = 1 << 20;
+
+struct BnfFwdArgs {
+    int N;
+    const float *X, *A, *f1, *f2, *m1, *m2;
+    float *out, *t2n, *t2pos, *lse, *q;
+    float slope;
+};
+
+// Block (b, 64 destination rows): wave w owns rows 16*w .. 16*w+15 and all H heads.
+template <int FP, int H, bool SAVE>
+__global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
+    constexpr int LD = FP + 4;
+    constexpr int NT = (FP + 15) / 16;
+    constexpr bool NARROW = FP < 16;
+    __shared__ __attribute__((aligned(16))) float xs[kBnfJC * LD];
+    __shared__ float f2s[kBnfJC * H];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int N = a.N;
+    const int64_t b = blockIdx.x;
+    const int i0 = blockIdx.y * 64 + wave * 16;
+    const int irow = min(i0 + m, N - 1);
+    const float *arow = a.A + (b * N + irow) * (int64_t)N;
+    const float *f2b = a.f2 + b * N * (int64_t)H;
+    const bool vec = (N & 3) == 0;
+    const float maskf = (!NARROW || m < FP) ? 1.f : 0.f;
+    const int mcl = (!NARROW || m < FP) ? m : 0;
+
+    float f1v[H], mx[H], m1v[H], m2v[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        f1v[h] = a.f1[(b * N + irow) * H + h];
+        mx[h] = -INFINITY;
+        m1v[h] = a.m1[h];
+        m2v[h] = a.m2[h];
+    }
+    // ---- sweep 1: row maxima of LeakyReLU(f1_i + f2_j) --------------------------------------
+    for (int jc = 0; jc < N; jc += kBnfJC) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < kBnfJC * H; e += 256) f2s[e] = (jc + e / H < N) ? f2b[(int64_t)jc * H + e] : -INFINITY;
+        __syncthreads();
+        const int jend = min(kBnfJC, N - jc);
+        for (int jl = 0; jl < jend; jl += 16)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int h = 0; h < H; ++h) mx[h] = fmaxf(mx[h], leaky(f1v[h] + f2s[(jl + 4 * kq + t) * H + h], a.slope));
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        mx[h] = fmaxf(mx[h], __shfl_xor(mx[h], 16, 64));
+        mx[h] = fmaxf(mx[h], __shfl_xor(mx[h], 32, 64));
+    }
+    // ---- sweep 2 ----------------------------------------------------------------------------------
+    f32x4 accU[NT], accV[NT], acc2[H][NT], acc2p[SAVE ? H : 1][NT];
+    float ssum[H], qsum[H];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) accU[nt] = accV[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        ssum[h] = qsum[h] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc2[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (SAVE) acc2p[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    for (int jc = 0; jc < N; jc += kBnfJC) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < kBnfJC * (FP / 4); e += 256) {
+            const int r = e / (FP / 4), c = e % (FP / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (jc + r < N) v = *reinterpret_cast<const float4 *>(a.X + (b * N + jc + r) * (int64_t)FP + 4 * c);
+            *reinterpret_cast<float4 *>(xs + r * LD + 4 * c) = v;
+        }
+        for (int e = threadIdx.x; e < kBnfJC * H; e += 256) f2s[e] = (jc + e / H < N) ? f2b[(int64_t)jc * H + e] : -INFINITY;
+        __syncthreads();
+        const int jend = min(kBnfJC, N - jc);
+        for (int jl = 0; jl < jend; jl += 16) {
+            const int j = jc + jl + 4 * kq;
+            float av[4];
+            if (vec && j < N) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(arow + j);
+                av[0] = t4.x; av[1] = t4.y; av[2] = t4.z; av[3] = t4.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) av[t] = (j + t < N) ? arow[j + t] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float *xrow = xs + (jl + 4 * kq + t) * LD;
+                float xr[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) xr[nt] = NARROW ? xrow[mcl] * maskf : xrow[16 * nt + m];
+                const float th = av[t] > 0.f ? 1.f : 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    accU[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(th, xr[nt], accU[nt], 0, 0, 0);
+                    accV[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], xr[nt], accV[nt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const float z = f1v[h] + f2s[(jl + 4 * kq + t) * H + h];     // -inf for j >= N => p = 0
+                    const float p = exp_neg(leaky(z, a.slope) - mx[h]);
+                    const bool ps = z > 0.f;
+                    ssum[h] += p;
+                    qsum[h] += ps ? p : 0.f;
+                    const float np_ = (m2v[h] * th + av[t]) * p;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc2[h][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(np_, xr[nt], acc2[h][nt], 0, 0, 0);
+                        if constexpr (SAVE) acc2p[h][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ps ? np_ : 0.f, xr[nt], acc2p[h][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (i0 >= N) return;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        ssum[h] += __shfl_xor(ssum[h], 16, 64); ssum[h] += __shfl_xor(ssum[h], 32, 64);
+        qsum[h] += __shfl_xor(qsum[h], 16, 64); qsum[h] += __shfl_xor(qsum[h], 32, 64);
+    }
+    // C layout: lane (kq, m) holds rows 4*kq + r, column 16*nt + m
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 4 * kq + r;
+            const float s = __shfl(ssum[h], 4 * kq + r, 64);
+            const float qv = __shfl(qsum[h], 4 * kq + r, 64);
+            const float mrow = __shfl(mx[h], 4 * kq + r, 64);
+            const float inv = s > 0.f ? 1.0f / s : 0.f;
+            if (i >= N) continue;
+            const int64_t node = b * N + i;
+            if constexpr (SAVE) {
+                if (m == 0) {
+                    a.lse[node * H + h] = mrow + logf(s);
+                    a.q[node * H + h] = qv * inv;
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = 16 * nt + m;
+                if (c < FP) {
+                    const int64_t o = (node * H + h) * FP + c;
+                    const float t2 = acc2[h][nt][r] * inv;
+                    a.out[o] = m1v[h] * (m2v[h] * accU[nt][r] + accV[nt][r]) + t2;
+                    if constexpr (SAVE) {
+                        a.t2n[o] = t2;
+                        a.t2pos[o] = acc2p[h][nt][r] * inv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct BnfBwdArgs {
+    int N;
+    const float *G, *stats, *X, *A, *f2, *m1, *m2;
+    float *dX, *dA, *df2, *ws;
+    float slope;
+};
+
+// Block (b, 64 sources): wave w owns sources 16*w .. 16*w+15, all heads, and walks all destinations.
+template <int FP, int H>
+__global__ __launch_bounds__(256) void bnf_attn_bwd_kernel(BnfBwdArgs a) {
+    constexpr int W = H * FP;
+    constexpr int LDG = W + 2;
+    constexpr int NT = (FP + 15) / 16;
+    constexpr int KS = FP / 4;
+    constexpr bool NARROW = FP < 16;
+    __shared__ __attribute__((aligned(16))) float gs[kBnfJC * LDG];       // G rows (all heads) of the destination chunk
+    __shared__ __attribute__((aligned(16))) float ss[kBnfJC * H * 4];     // {f1, lse, c, -}
+    __shared__ float red[4][2 * H];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int N = a.N;
+    const int64_t b = blockIdx.x;
+    const int j0 = blockIdx.y * 64 + wave * 16;
+    const int jcol = min(j0 + m, N - 1);
+    const bool jok = j0 + m < N;
+    const float maskf = (!NARROW || m < FP) ? 1.f : 0.f;
+    const int mcl = (!NARROW || m < FP) ? m : 0;
+
+    float f2v[H], df2[H], dm1[H], dm2[H], m1v[H], m2v[H], xb[KS];
+    f32x4 acc[NT];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        f2v[h] = a.f2[(b * N + jcol) * H + h];
+        df2[h] = dm1[h] = dm2[h] = 0.f;
+        m1v[h] = a.m1[h];
+        m2v[h] = a.m2[h];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xb[s] = a.X[(b * N + jcol) * (int64_t)FP + 4 * s + kq];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int ic = 0; ic < N; ic += kBnfJC) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < kBnfJC * (W / 2); e += 256) {
+            const int r = e / (W / 2), c = e % (W / 2);
+            float2 v = make_float2(0.f, 0.f);
+            if (ic + r < N) v = *reinterpret_cast<const float2 *>(a.G + (b * N + ic + r) * (int64_t)W + 2 * c);
+            *reinterpret_cast<float2 *>(gs + r * LDG + 2 * c) = v;
+        }
+        for (int e = threadIdx.x; e < kBnfJC * H; e += 256) {
+            const int r = e / H, h = e % H;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ic + r < N) {
+                const float *st = a.stats + (b * N + ic + r) * (int64_t)(3 * H) + h;
+                v = make_float4(st[0], st[H], st[2 * H], 0.f);
+            }
+            *reinterpret_cast<float4 *>(ss + e * 4) = v;
+        }
+        __syncthreads();
+        if (j0 >= N) continue;
+        const int iend = min(kBnfJC, N - ic);
+        for (int il = 0; il < iend; il += 16) {
+            float av[4], th[4], dA[4];
+            bool ok[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ic + il + 4 * kq + r;
+                ok[r] = i < N && jok;
+                av[r] = ok[r] ? a.A[(b * N + i) * (int64_t)N + jcol] : 0.f;
+                th[r] = av[r] > 0.f ? 1.f : 0.f;
+                dA[r] = 0.f;
+            }
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                f32x4 D = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    D = __builtin_amdgcn_mfma_f32_16x16x4f32(gs[(il + m) * LDG + h * FP + 4 * s + kq], xb[s], D, 0, 0, 0);
+                float wv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 st = *reinterpret_cast<const float4 *>(ss + ((il + 4 * kq + r) * H + h) * 4);
+                    const float z = st.x + f2v[h];
+                    const float C = ok[r] ? exp_neg(leaky(z, a.slope) - st.y) : 0.f;
+                    const float n = m2v[h] * th[r] + av[r];
+                    const float dn = (m1v[h] + C) * D[r];
+                    wv[r] = ok[r] ? n * (m1v[h] + C) : 0.f;
+                    if (ok[r]) {
+                        dA[r] += dn;
+                        dm1[h] += n * D[r];
+                        dm2[h] += th[r] * dn;
+                    }
+                    df2[h] += C * (n * D[r] - st.z) * (z > 0.f ? 1.f : a.slope);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float *grow = gs + (il + 4 * kq + r) * LDG + h * FP;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float bval = NARROW ? grow[mcl] * maskf : grow[16 * nt + m];
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[r], bval, acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ic + il + 4 * kq + r;
+                if (ok[r]) a.dA[(b * N + i) * (int64_t)N + jcol] = dA[r];
+            }
+        }
+    }
+    // per-wave totals of dm1 / dm2 -> block partial (fixed order) -> ws[block][2H]
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float u = dm1[h], v = dm2[h];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            u += __shfl_xor(u, o, 64);
+            v += __shfl_xor(v, o, 64);
+        }
+        if (lane == 0) {
+            red[wave][h] = u;
+            red[wave][H + h] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * H) {
+        const int64_t blk = (int64_t)blockIdx.x * gridDim.y + blockIdx.y;
+        a.ws[blk * 2 * H + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+    if (j0 >= N) return;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float t = df2[h];
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        if (kq == 0 && jok) a.df2[(b * N + j0 + m) * H + h] = t;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + 4 * kq + r;
+        if (j >= N) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = 16 * nt + m;
+            if (c < FP) a.dX[(b * N + j) * (int64_t)FP + c] = acc[nt][r];
+        }
+    }
+}
+
+__global__ void bnf_dm_reduce_kernel(const float *ws, int nblocks, int width, float *out) {
+    const int c = blockIdx.x * kSumCols + threadIdx.x;
+    const bool ok = c < width;
+    const float t = block_column_sum(nblocks, [&](int r) { return ok ? ws[(int64_t)r * width + c] : 0.f; });
+    if (ok && threadIdx.y == 0) out[c] = t;
+}
+
+#define GATMI_BNF_SHAPES(X) X(4, 1) X(4, 2) X(8, 1) X(8, 2) X(16, 1) X(16, 2) X(32, 1) X(32, 2) X(64, 1) X(64, 2)
+
+}  // namespace gatmi
+
+using namespace gatmi;
+
+static int bnf_check(int64_t B, int32_t N, int32_t H, int32_t fp, const char *name) {
+    GATMI_REQUIRE(B >= 0 && N >= 0, GATMI_EINVAL, "%s: negative size", name);
+    GATMI_REQUIRE((fp == 4 || fp == 8 || fp == 16 || fp == 32 || fp == 64) && (H == 1 || H == 2), GATMI_EUNSUPPORTED,
+                  "%s: feature width %d (4..64, power of two) with %d heads (1 or 2) not built", name, fp, H);
+    GATMI_REQUIRE(B <= 0x7fffffff && (int64_t)B * ((N + 63) / 64) < kBnfBlocksMax * 64LL, GATMI_ERANGE, "%s: batch too large for one launch", name);
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
+                                  const float *X, const float *A, const float *f1, const float *f2,
+                                  const float *m1, const float *m2, float slope,
+                                  float *out, float *t2n, float *t2pos, float *lse, float *q, void *stream) {
+    int rc = bnf_check(B, N, H, fp, "bnf_attn_fwd");
+    if (rc) return rc;
+    if (B == 0 || N == 0) return GATMI_OK;
+    GATMI_REQUIRE(X && A && f1 && f2 && m1 && m2 && out, GATMI_EINVAL, "bnf_attn_fwd: null pointer");
+    const bool save = t2n || t2pos || lse || q;
+    GATMI_REQUIRE(!save || (t2n && t2pos && lse && q), GATMI_EINVAL, "bnf_attn_fwd: t2n, t2pos, lse, q must be given together");
+    GATMI_REQUIRE_ALIGNED(X); GATMI_REQUIRE_ALIGNED(A);
+    BnfFwdArgs a;
+    a.N = N; a.X = X; a.A = A; a.f1 = f1; a.f2 = f2; a.m1 = m1; a.m2 = m2;
+    a.out = out; a.t2n = t2n; a.t2pos = t2pos; a.lse = lse; a.q = q; a.slope = slope;
+    const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define X_(ff, hh)                                                                                  \
+    if (fp == ff && H == hh) {                                                                      \
+        if (save) hipLaunchKernelGGL((bnf_attn_fwd_kernel<ff, hh, true>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((bnf_attn_fwd_kernel<ff, hh, false>), grid, dim3(256), 0, st, a);     \
+        GATMI_LAUNCH_CHECK("bnf_attn_fwd");                                                         \
+        return GATMI_OK;                                                                            \
+    }
+    GATMI_BNF_SHAPES(X_)
+#undef X_
+    return fail(GATMI_EUNSUPPORTED, "bnf_attn_fwd: no kernel for fp=%d H=%d", fp, H);
+}
+
+extern "C" size_t gatmi_bnf_attn_bwd_ws_floats(int64_t B, int32_t N, int32_t H) {
+    return (size_t)B * (size_t)((N + 63) / 64) * (size_t)(2 * H);
+}
+
+extern "C" int gatmi_bnf_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t fp,
+                                  const float *G, const float *stats, const float *X, const float *A,
+                                  const float *f2, const float *m1, const float *m2, float slope,
+                                  float *dX, float *dA, float *df2, float *dm, float *ws, void *stream) {
+    int rc = bnf_check(B, N, H, fp, "bnf_attn_bwd");
+    if (rc) return rc;
+    if (B == 0 || N == 0) return GATMI_OK;
+    GATMI_REQUIRE(G && stats && X && A && f2 && m1 && m2 && dX && dA && df2 && dm && ws, GATMI_EINVAL, "bnf_attn_bwd: null pointer");
+    GATMI_REQUIRE_ALIGNED(G);
+    BnfBwdArgs a;
+    a.N = N; a.G = G; a.stats = stats; a.X = X; a.A = A; a.f2 = f2; a.m1 = m1; a.m2 = m2;
+    a.dX = dX; a.dA = dA; a.df2 = df2; a.ws = ws; a.slope = slope;
+    const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define X_(ff, hh)                                                                         \
+    if (fp == ff && H == hh) {                                                             \
+        hipLaunchKernelGGL((bnf_attn_bwd_kernel<ff, hh>), grid, dim3(256), 0, st, a);       \
+        GATMI_LAUNCH_CHECK("bnf_attn_bwd");                                                \
+        const int nblocks = (int)(grid.x * grid.y);                                        \
+        hipLaunchKernelGGL(bnf_dm_reduce_kernel, dim3(1), dim3(kSumCols, kSumRows), 0, st, ws, nblocks, 2 * hh, dm); \
+        GATMI_LAUNCH_CHECK("bnf_dm_reduce");                                               \
+        return GATMI_OK;                                                                   \
+    }
+    GATMI_BNF_SHAPES(X_)
+#undef X_
+    return fail(GATMI_EUNSUPPORTED, "bnf_attn_bwd: no kernel for fp=%d H=%d", fp, H);
+}

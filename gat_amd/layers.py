@@ -176,3 +176,38 @@ def sp_attn_head(seq, out_sz, adj_mat, activation, nb_nodes, in_drop=0.0, coef_d
     (indices, values, shape) triple of preprocess_adj_bias (utils/process.py:188) or a CSRGraph."""
     training = in_drop != 0.0 or coef_drop != 0.0
     return sp_attn_heads(seq, out_sz, adj_mat, activation, nb_nodes, 1, "concat", in_drop, coef_drop, residual, training)
+
+
+class BNFAttention(nn.Module):
+    """The attention step of the brain-network models: one `attn_v2e_BNF_V2` coefficient matrix per
+    head (utils/layers.py:229-237: conv1d to feat_dim without bias, two conv1d(.,1,1) logit halves,
+    LeakyReLU, unmasked softmax) combined with the weighted adjacency as in the loop body of
+    `attn_e2v_BNF_V2` (:174-179):  agg = ((net_mat>0)*m2 + net_mat) * (m1 + coefs) @ seq.
+    Returns [B, N, heads, F]; the surrounding conv1d / concat layers of the reference are ordinary
+    dense layers and stay in the host framework."""
+
+    def __init__(self, f_in, heads, feat_dim=64, device=None):
+        super().__init__()
+        self.f_in, self.heads, self.feat_dim = int(f_in), int(heads), int(feat_dim)
+        kw = {"device": device, "dtype": torch.float32}
+        self.W = nn.Parameter(torch.empty(f_in, heads, feat_dim, **kw))
+        self.a1 = nn.Parameter(torch.empty(heads, feat_dim, **kw))
+        self.a2 = nn.Parameter(torch.empty(heads, feat_dim, **kw))
+        self.b1 = nn.Parameter(torch.zeros(heads, **kw))
+        self.b2 = nn.Parameter(torch.zeros(heads, **kw))
+        self.m1 = nn.Parameter(torch.ones(heads, **kw))      # stimulate_mag_1, layers.py:175
+        self.m2 = nn.Parameter(torch.ones(heads, **kw))      # stimulate_mag_2, layers.py:177
+        lim_w = math.sqrt(6.0 / (f_in + feat_dim))
+        lim_a = math.sqrt(6.0 / (feat_dim + 1))
+        with torch.no_grad():
+            self.W.uniform_(-lim_w, lim_w)
+            self.a1.uniform_(-lim_a, lim_a)
+            self.a2.uniform_(-lim_a, lim_a)
+
+    def forward(self, seq, net_mat):
+        outs = []
+        for h0 in range(0, self.heads, 2):                   # the kernels take one or two heads per sweep
+            s = slice(h0, min(h0 + 2, self.heads))
+            outs.append(ops.bnf_aggregate(seq, net_mat, self.W[:, s].contiguous(), self.a1[s], self.a2[s], self.b1[s],
+                                          self.b2[s], self.m1[s], self.m2[s]))
+        return torch.cat(outs, dim=2)

@@ -210,6 +210,29 @@ int gatmi_dense_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t dp,
                          float slope, float coef_keep, float feat_keep, uint64_t seed,
                          float *dWh, float *df2, void *stream);
 
+/* Brain-network variant of the attention step: the inner loop body of attn_e2v_BNF_V2
+ * (utils/layers.py:174-179) with the coefficients of attn_v2e_BNF_V2 (:229-237), for H heads that
+ * share X and the weighted adjacency A but own their projection (f1, f2) and the scalars m1, m2
+ * (stimulate_mag_1 / _2):
+ *     out[b,i,h,:] = sum_j (m2[h]*[A_ij > 0] + A_ij) * (m1[h] + softmax_j(LeakyReLU(f1_i + f2_j))) * X[b,j,:]
+ *   X [B,N,fp] (fp = feature width padded to 4, 8, 16, 32 or 64; padded columns zero), A [B,N,N],
+ *   f1,f2 [B,N,H] (from gatmi_proj_fwd), m1,m2 [H] in DEVICE memory, H = 1 or 2;
+ *   out [B,N,H,fp]; t2n, t2pos [B,N,H,fp], lse, q [B,N,H]: saved for backward, or all NULL. */
+int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
+                       const float *X, const float *A, const float *f1, const float *f2,
+                       const float *m1, const float *m2, float slope,
+                       float *out, float *t2n, float *t2pos, float *lse, float *q, void *stream);
+
+/* Backward of the above.  G [B,N,H,fp] = gradient of out; stats [B,N,3,H] = {f1, lse, c} with
+ * c = <G, t2n> per head, as written by gatmi_gat_bwd_node(dout = G, agg = t2n, pos = t2pos, identity),
+ * which also yields df1.  Outputs: dX [B,N,fp] (aggregation part only), dA [B,N,N], df2 [B,N,H],
+ * dm [2H] = {dm1[H], dm2[H]}.  ws: gatmi_bnf_attn_bwd_ws_floats(B, N, H) floats. */
+size_t gatmi_bnf_attn_bwd_ws_floats(int64_t B, int32_t N, int32_t H);
+int gatmi_bnf_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t fp,
+                       const float *G, const float *stats, const float *X, const float *A,
+                       const float *f2, const float *m1, const float *m2, float slope,
+                       float *dX, float *dA, float *df2, float *dm, float *ws, void *stream);
+
 /* Halo exchange helpers (row-partitioned multi-GPU).  pack: dst[k, :] = src[idx[k], :] for
  * k < n_idx, rows of `width` floats (send buffer of Wh / f2 rows requested by a peer); rows are
  * moved 16 bytes per lane when width is a multiple of 4, one float per lane otherwise.

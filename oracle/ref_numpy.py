@@ -250,3 +250,25 @@ def preprocess_features(features):
         r_inv = np.power(rowsum, -1).flatten()
     r_inv[np.isinf(r_inv)] = 0.0
     return np.asarray(sp.diags(r_inv).dot(features).todense())
+
+
+# --------------------------------------------------------------------------------------------
+# brain-network variant: utils/layers.py:171-179 with :229-237
+# --------------------------------------------------------------------------------------------
+def bnf_v2e_aggregate(x, net_mat, p):
+    """Loop-level numpy restatement of the inner step of attn_e2v_BNF_V2 for one graph batch.
+    x [B,N,F]; net_mat [B,N,N]; p: W [F,H,Dz], a1,a2 [H,Dz], b1,b2,m1,m2 [H].  Returns [B,N,H,F]."""
+    B, n, Fin = x.shape
+    H, Dz = p["a1"].shape
+    out = np.zeros((B, n, H, Fin), dtype=x.dtype)
+    for b in range(B):
+        thr = (net_mat[b] > 0).astype(x.dtype)                              # layers.py:168
+        for h in range(H):
+            seq = x[b] @ p["W"][:, h, :]                                    # :231
+            f_1 = seq @ p["a1"][h] + p["b1"][h]                             # :232
+            f_2 = seq @ p["a2"][h] + p["b2"][h]                             # :233
+            coefs = softmax_lastaxis(leaky_relu(f_1[:, None] + f_2[None, :]))   # :234-237
+            att = np.ones((n, n), dtype=x.dtype) * p["m1"][h] + coefs       # :176
+            net1 = thr * p["m2"][h] + net_mat[b]                            # :178
+            out[b, :, h, :] = (net1 * att) @ x[b]                           # :179
+    return out

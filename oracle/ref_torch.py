@@ -95,3 +95,30 @@ def inference_dense(x, layers, bias_mat, activation="elu", residual=False):
     for lp in layers[1:-1]:
         h = layer_dense(h, lp, bias_mat, activation, "concat", residual)
     return layer_dense(h, layers[-1], bias_mat, "identity", "mean", False)
+
+
+def bnf_v2e_aggregate(x, net_mat, p):
+    """Inner step of attn_e2v_BNF_V2 (utils/layers.py:171-179) with the coefficients of
+    attn_v2e_BNF_V2 (:229-237), for H "heads" that each own a projection, written with
+    differentiable torch ops.
+
+    x [B,N,F]; net_mat [B,N,N] weighted adjacency; p: W [F,H,Dz], a1,a2 [H,Dz], b1,b2 [H],
+    m1,m2 [H] (stimulate_mag_1 / _2, initialised to one in the reference).
+      seq  = conv1d(x, Dz, 1, use_bias=False)                      :231
+      f_1, f_2 = conv1d(seq, 1, 1) twice                           :232-233
+      coefs = softmax(leaky_relu(f_1 + f_2^T))      (UNmasked)     :234-237
+      att  = ones * m1 + coefs                                     :176
+      net1 = (net_mat > 0) * m2 + net_mat                          :168,178
+      agg  = (net1 * att) @ x                                      :179
+    Returns agg [B,N,H,F]."""
+    B, n, Fin = x.shape
+    H, Dz = p["a1"].shape
+    z = (x @ p["W"].reshape(Fin, H * Dz)).reshape(B, n, H, Dz)
+    f1 = (z * p["a1"]).sum(-1) + p["b1"]                       # [B,N,H]
+    f2 = (z * p["a2"]).sum(-1) + p["b2"]
+    logits = f1.permute(0, 2, 1)[:, :, :, None] + f2.permute(0, 2, 1)[:, :, None, :]   # [B,H,i,j]
+    coefs = torch.softmax(F.leaky_relu(logits, LEAKY_SLOPE), dim=-1)
+    att = p["m1"][None, :, None, None] + coefs
+    thr = (net_mat > 0).to(x.dtype)
+    net1 = thr[:, None] * p["m2"][None, :, None, None] + net_mat[:, None]
+    return torch.einsum("bhij,bjf->bihf", net1 * att, x)
