@@ -80,23 +80,63 @@ class GATHeads(nn.Module):
         training = self.training if training is None else training
         H, D = self.heads, self.width
         act = _activation_name(activation)
+        if isinstance(graph_or_bias, CSRGraph) and seq.dim() == 3:           # batch is 1 on the sparse path
+            return self.forward(seq[0], graph_or_bias, act, reduce, in_drop, coef_drop, training, seed)[None]
         if training and in_drop > 0.0:
             seq = torch.nn.functional.dropout(seq, in_drop, True)            # layers.py:8-9
-        wr = self.W_res if self.has_res else None
-        br = self.b_res if self.has_res else None
+        if seed is None and training and (in_drop > 0.0 or coef_drop > 0.0):
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        groups = _head_groups(H, D)
+        if len(groups) == 1:
+            return self._run(seq, graph_or_bias, slice(0, H), act, reduce, in_drop, coef_drop, training, seed)
+        # head counts the fused kernels do not take in one sweep (not a power of two, or too wide):
+        # power-of-two groups of heads, concatenated (and averaged afterwards if asked to)
+        if act != "identity" and reduce == "mean":
+            raise ValueError("mean over heads is defined for the identity activation (models/sp_gat.py:30-32)")
+        outs = [self._run(seq, graph_or_bias, slice(h0, h0 + hn), act, "concat", in_drop, coef_drop, training,
+                          None if seed is None else seed + h0) for h0, hn in groups]
+        out = torch.cat(outs, dim=-1)
+        if reduce == "mean":
+            out = out.reshape(*out.shape[:-1], H, D).mean(-2)
+        return out
+
+    def _run(self, seq, graph_or_bias, hs, act, reduce, in_drop, coef_drop, training, seed):
+        """One fused sweep over the heads in slice hs."""
+        hn, D = hs.stop - hs.start, self.width
+        sl = lambda t: t[hs] if hn != self.heads else t
+        W = self.W[:, hs] if hn != self.heads else self.W
+        wr = (self.W_res[:, hs] if hn != self.heads else self.W_res) if self.has_res else None
+        br = sl(self.b_res) if self.has_res else None
         if isinstance(graph_or_bias, CSRGraph):
-            x = seq[0] if seq.dim() == 3 else seq                           # batch is 1 on the sparse path
-            if not ops.supported_shape(H, D):
-                raise ValueError("heads=%d width=%d not supported by the fused kernels" % (H, D))
-            cfg = ops.make_cfg(H, D, act, reduce, coef_drop, in_drop, training, seed)
-            out = ops.sparse_gat_layer(x, self.W, self.a1, self.a2, self.b1, self.b2, self.bias, graph_or_bias, cfg, wr, br)
-            return out[None] if seq.dim() == 3 else out
-        cfg = ops.make_cfg(H, D, act, "concat", coef_drop, in_drop, training, seed)
-        out = ops.dense_gat_layer(seq, self.W, self.a1, self.a2, self.b1, self.b2, self.bias, graph_or_bias, cfg, wr, br)
+            cfg = ops.make_cfg(hn, D, act, reduce, coef_drop, in_drop, training, seed)
+            return ops.sparse_gat_layer(seq, W, sl(self.a1), sl(self.a2), sl(self.b1), sl(self.b2), sl(self.bias),
+                                        graph_or_bias, cfg, wr, br)
+        cfg = ops.make_cfg(hn, D, act, "concat", coef_drop, in_drop, training, seed)
+        out = ops.dense_gat_layer(seq, W, sl(self.a1), sl(self.a2), sl(self.b1), sl(self.b2), sl(self.bias),
+                                  graph_or_bias, cfg, wr, br)
         if reduce == "mean":
             B, N = out.shape[:2]
-            out = out.reshape(B, N, H, D).mean(2)
+            out = out.reshape(B, N, hn, D).mean(2)
         return out
+
+
+def _head_groups(H, D):
+    """Split H heads into runs (start, count) whose count is a power of two with
+    count * padded_width(D) <= 256, largest first: 6 heads of width 8 -> (0,4), (4,2)."""
+    dp = ops.padded_width(D)
+    if dp > 256:
+        raise ValueError("head width %d is beyond the kernels' 256-column rows" % D)
+    cap = 1
+    while cap * 2 * dp <= 256:
+        cap *= 2
+    groups, h0 = [], 0
+    while h0 < H:
+        g = cap
+        while g > H - h0:
+            g //= 2
+        groups.append((h0, g))
+        h0 += g
+    return groups
 
 
 # ------------------------------------------------------------------------------------------------

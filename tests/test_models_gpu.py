@@ -128,3 +128,31 @@ def test_cpu_tensors_are_rejected_loudly():
     z = torch.zeros
     with pytest.raises(RuntimeError, match="GPU only"):
         ops.sparse_gat_layer(z(n, 4), z(4, 1, 4), z(1, 4), z(1, 4), z(1), z(1), z(1, 4), g, ops.make_cfg(1, 4))
+
+
+def test_head_counts_outside_the_fused_shapes_run_in_groups():
+    """6 heads (BNF_AE.py:18) is not a power of two: the layer runs as a 4-head and a 2-head sweep."""
+    from gat_amd import CSRGraph
+    from gat_amd.layers import GATHeads, _head_groups
+    from tests.util import layer_params
+    assert _head_groups(6, 8) == [(0, 4), (4, 2)] and _head_groups(8, 8) == [(0, 8)] and _head_groups(3, 64) == [(0, 2), (2, 1)]
+    dev = torch.device("cuda:0")
+    n, F, H, D = 150, 12, 6, 8
+    dst, src = random_graph(n, 4.0, seed=3)
+    p = layer_params(F, H, D, seed=9)
+    m = GATHeads(F, H, D, device=dev)
+    m.load(p)
+    x = np.random.default_rng(1).normal(0, 1, (n, F))
+    xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
+    rowptr, col = ref_numpy.coo_to_csr(np.stack([dst, src], 1), n)
+    g = CSRGraph.from_coo(dst, src, n, dev)
+    out = m(xt, g, "elu", "concat")
+    assert_close(out.detach().cpu().numpy(), ref_numpy.gat_layer_csr(x, p, rowptr, col, ref_numpy.elu, "concat"), what="6 heads concat")
+    out.sum().backward()
+    assert m.W.grad is not None and torch.isfinite(m.W.grad).all() and (m.W.grad.abs().sum((0, 2)) > 0).all()
+    mean = m(xt, g, "identity", "mean")
+    assert_close(mean.detach().cpu().numpy(), ref_numpy.gat_layer_csr(x, p, rowptr, col, ref_numpy.identity, "mean"), what="6 heads mean")
+    bm = np.full((1, n, n), -1e9, dtype=np.float32)
+    bm[0, dst, src] = 0.0
+    dense = m(xt[None], torch.tensor(bm, device=dev), "elu", "concat")
+    assert_close(dense[0].detach().cpu().numpy(), out.detach().cpu().numpy(), rtol=2e-6, atol_scale=1e-6, what="6 heads dense")
