@@ -35,13 +35,19 @@ def rmat_graph(n, n_edges, seed, device, abcd=RMAT_ABCD, row_range=None):
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     lo, hi = (0, n) if row_range is None else row_range
+    mult = 1_000_003
+    while math.gcd(mult, n) != 1:
+        mult += 2
     keys = torch.empty(0, dtype=torch.int64, device=device)
     batch = max(1 << 16, int(n_edges * 0.35))
     while keys.numel() < n_edges:
         dst, src = _rmat_batch(batch, scale, gen, device, abcd)
         if row_range is not None:
-            # draw destinations inside the range: keep the R-MAT column skew, remap the row
+            # one partition's rows: destinations are folded into the range; source ids go through a
+            # fixed affine bijection of [0, n) so that the R-MAT hubs (the low ids) are spread over
+            # all owners instead of piling up on the first partition (a random node labelling)
             dst = lo + dst % (hi - lo)
+            src = torch.where(src < n, (src * mult + 12345) % n, src)
         ok = (dst < n) & (src < n) & (dst != src)
         k = dst[ok] * n + src[ok]
         keys = torch.unique(torch.cat([keys, k]))
