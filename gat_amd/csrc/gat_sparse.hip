@@ -76,16 +76,14 @@ __device__ __forceinline__ void fwd_batch(RowState &st, const FwdArgs &a, const 
         mn = fmaxf(mn, e[t]);
     }
     const float sc = exp_neg(st.m - mn);  // 0 on the first batch (m = -inf)
-    st.s *= sc;
-    st.acc = f4_scale(sc, st.acc);
-    if (SAVE) {
-        st.q *= sc;
-        st.pos = f4_scale(sc, st.pos);
-    }
+    // The batch is summed on its own and then added to the running sums: the long accumulators
+    // take one rounding per batch instead of one per neighbour (rows of 10^4..10^5 entries).
+    float bs = 0.f, bq = 0.f;
+    float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f), bpos = bacc;
 #pragma unroll
     for (int t = 0; t < U; ++t) {
         const float p = exp_neg(e[t] - mn);
-        st.s += p;
+        bs += p;
         float pa = p;
         float4 vv = v[t];
         if (DROP) {
@@ -93,12 +91,18 @@ __device__ __forceinline__ void fwd_batch(RowState &st, const FwdArgs &a, const 
                 pa = keep_mask(a.seed, (uint64_t)(epos + t) * H + head, a.coef_keep) ? p / a.coef_keep : 0.f;
             if (a.feat_keep < 1.f) vv = drop_feat(vv, a.seed, j[t], HD, sub * 4, a.feat_keep);
         }
-        st.acc = f4_fma(pa, vv, st.acc);
+        bacc = f4_fma(pa, vv, bacc);
         if (SAVE) {
             const bool ps = z[t] > 0.f;
-            st.q += ps ? p : 0.f;
-            st.pos = f4_fma(ps ? pa : 0.f, vv, st.pos);
+            bq += ps ? p : 0.f;
+            bpos = f4_fma(ps ? pa : 0.f, vv, bpos);
         }
+    }
+    st.s = fmaf(st.s, sc, bs);
+    st.acc = f4_fma(sc, st.acc, bacc);
+    if (SAVE) {
+        st.q = fmaf(st.q, sc, bq);
+        st.pos = f4_fma(sc, st.pos, bpos);
     }
     st.m = mn;
 }
@@ -327,6 +331,8 @@ __device__ __forceinline__ void bwd_batch(SrcState &st, const BwdCscArgs &a, con
         lsev[t] = s[H];
         cv[t] = s[2 * H];
     }
+    float bdf2 = 0.f;
+    float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int t = 0; t < U; ++t) {
         const float z = f1v[t] + f2v;
@@ -342,9 +348,11 @@ __device__ __forceinline__ void bwd_batch(SrcState &st, const BwdCscArgs &a, con
             }
         }
         const float dz = alpha * (dalpha - cv[t]) * (z > 0.f ? 1.f : a.slope);
-        st.acc = f4_fma(aa, gv[t], st.acc);
-        st.df2 += dz;
+        bacc = f4_fma(aa, gv[t], bacc);
+        bdf2 += dz;
     }
+    st.acc = f4_add(st.acc, bacc);      // one rounding of the long sums per batch, not per entry
+    st.df2 += bdf2;
 }
 
 template <int G, int LPH, bool DROP>

@@ -1,0 +1,87 @@
+"""Size-independent properties checked at the benchmark's full size (R-MAT graph at the
+ogbn-products shape: 2.45 M nodes, 64.3 M stored entries, hub rows of tens of thousands of
+entries that go through the split-and-merge path), where the oracle would take far too long:
+
+  * constant features  => every coefficient row sums to 1, so out = act(Wh + bias) at every node
+  * sum_j dWh_j (attention part) == sum_i g_i                 (coefficient rows sum to 1)
+  * sum_j df2_j == sum_i df1_i                                (both are the sum of all dlogit_ij;
+                                                                df1 comes from the forward pass's
+                                                                positive-part sums, df2 from the CSC sweep)
+  * the layer is deterministic: two runs agree bit for bit
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H, D, F = 8, 8, 100
+
+
+@pytest.fixture(scope="module")
+def big():
+    from gat_amd import CSRGraph, synth
+    dev = torch.device("cuda:0")
+    n, e = synth.PRODUCTS_NODES, synth.PRODUCTS_EDGES
+    dst, src = synth.rmat_graph(n, e, 4, dev)
+    g = CSRGraph.from_device_coo(dst, src, n, n)
+    del dst, src
+    assert g.nnz == e + n and len(g.split_csr) > 0 and len(g.split_csc) > 0
+    return g, dev
+
+
+def test_constant_features_give_constant_output(big):
+    from gat_amd import ops, synth
+    g, dev = big
+    n = g.n_dst
+    p = synth.glorot_layer(F, H, D, 7, dev, zero_bias=False)
+    x = torch.ones(n, F, device=dev)
+    out = ops.sparse_gat_layer(x, p["W"], p["a1"], p["a2"], p["b1"], p["b2"], p["bias"], g, ops.make_cfg(H, D, "elu"))
+    want = torch.nn.functional.elu(p["W"].double().sum(0).reshape(-1) + p["bias"].double().reshape(-1))
+    err = (out.double() - want[None]).abs().max().item()
+    assert err <= 1e-5 * want.abs().max().item(), err
+
+
+def test_gradient_checksums_and_determinism(big):
+    from gat_amd import _lib, ops, synth
+    from gat_amd._lib import ptr
+    g, dev = big
+    n = g.n_dst
+    hd = H * D
+    p = synth.glorot_layer(F, H, D, 7, dev, zero_bias=False)
+    x = synth.normal((n, F), 5, dev)
+    dout = synth.normal((n, hd), 8, dev)
+    cfg = ops.make_cfg(H, D, "elu")
+    st = _lib.current_stream()
+    new = lambda *s: torch.empty(*s, device=dev)
+    Wp, a1p, a2p, _, Wh, f1, f2, _ = ops._project(x, p["W"], p["a1"], p["a2"], p["b1"], p["b2"], cfg)
+    outs = []
+    for _ in range(2):
+        out, agg, pos, lse, q = new(n, hd), new(n, hd), new(n, hd), new(n, H), new(n, H)
+        ws = new(_lib.lib.gatmi_gat_fwd_ws_floats(g.n_slots_csr, H, D))
+        _lib.call("gatmi_gat_fwd", n, H, D, ptr(g.items_csr), len(g.items_csr), ptr(g.split_csr), len(g.split_csr),
+                  ptr(g.col), ptr(Wh), ptr(f1), ptr(f2), ptr(p["bias"].reshape(-1).contiguous()), None,
+                  _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, 1.0, 1.0, 0, ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
+        gg, stats, df1, dbias = new(n, hd), new(n, 3 * H), new(n, H), new(hd)
+        wsn = new(_lib.lib.gatmi_gat_bwd_node_ws_floats(H, D))
+        _lib.call("gatmi_gat_bwd_node", n, H, D, ptr(dout), ptr(out), ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse),
+                  _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(gg), ptr(stats), ptr(df1), ptr(dbias), ptr(wsn), st)
+        dfeat, df2 = new(n, hd), new(n, H)
+        wsb = new(_lib.lib.gatmi_gat_bwd_ws_floats(g.n_slots_csc, H, D))
+        _lib.call("gatmi_gat_bwd_csc", n, H, D, ptr(g.items_csc), len(g.items_csc), ptr(g.split_csc), len(g.split_csc),
+                  ptr(g.rowidx), None, ptr(gg), ptr(stats), ptr(Wh), ptr(f2), None, None, None,
+                  0.2, 1.0, 1.0, 0, ptr(dfeat), ptr(df2), ptr(wsb), st)
+        outs.append((out, dfeat, df2, df1, dbias, gg))
+    (out, dfeat, df2, df1, dbias, gg), second = outs
+    for a, b in zip(outs[0], second):
+        assert torch.equal(a, b), "two runs differ"
+    assert torch.isfinite(out).all() and torch.isfinite(dfeat).all()
+    # coefficient rows sum to one: column sums of the transposed aggregation equal those of g
+    lhs, rhs = dfeat.double().sum(0), gg.double().sum(0)
+    scale = gg.double().abs().sum(0)
+    assert ((lhs - rhs).abs() <= 1e-6 * scale).all(), ((lhs - rhs).abs() / scale).max().item()
+    assert ((dbias.double() - rhs).abs() <= 1e-6 * scale).all()
+    # both logit-gradient vectors add up to the same total
+    l2, r2 = df2.double().sum(0), df1.double().sum(0)
+    s2 = df2.double().abs().sum(0) + df1.double().abs().sum(0)
+    assert ((l2 - r2).abs() <= 1e-6 * s2).all(), ((l2 - r2).abs() / s2).max().item()
