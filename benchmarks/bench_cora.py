@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Secondary measurement: BASELINE.json configs[0] and configs[1] — the two-layer Cora network
+(2708 nodes, 1433 features, 8 heads x 8 hidden, 7 classes; execute_cora.py:13-22) through
+GAT.inference (dense bias_mat) and SpGAT.inference (sparse adjacency), forward + backward, next
+to the CPU restatement of the dense path (oracle/ref_torch.py, torch-CPU fp32; the reference's
+TensorFlow is not installed).  The graph is the reference's own random stand-in for Cora
+(utils/process.py:98-123 style: symmetric, density 0.002, plus self-loops)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def timed(fn, iters, sync):
+    for _ in range(3):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def main():
+    from gat_amd import CSRGraph, layers, preprocess
+    from gat_amd.models import GAT, SpGAT
+    from oracle import ref_torch
+    dev = torch.device("cuda:0")
+    n, f, c = 2708, 1433, 7
+    rng = np.random.RandomState(0)
+    adj = sp.random(n, n, density=0.001, random_state=rng, format="csr")
+    adj = ((adj + adj.T) > 0).astype(np.float64)
+    feats = preprocess.preprocess_features(sp.random(n, f, density=0.0127, random_state=rng, format="csr"))[0]
+    triple = preprocess.preprocess_adj_bias(adj)
+    graph = CSRGraph.from_reference_triple(triple, dev)
+    bias = torch.tensor(preprocess.adj_to_bias(np.asarray(adj.todense())[None], [n], 1), dtype=torch.float32, device=dev)
+    x = torch.tensor(np.asarray(feats)[None], dtype=torch.float32, device=dev)
+    kw = dict(hid_units=[8], n_heads=[8, 1], activation=layers.elu, residual=False)
+    res = {"nodes": n, "entries": graph.nnz}
+    for name, model, g in (("sparse", SpGAT, graph), ("dense", GAT, bias)):
+        store = layers.VariableStore()
+
+        def step():
+            with layers.variable_scope(store):
+                out = model.inference(x, c, n, False, 0.0, 0.0, bias_mat=g, **kw)
+            for p in store.parameters():
+                p.grad = None
+            out.sum().backward()
+        res[name + "_gpu_ms"] = round(timed(step, 20, torch.cuda.synchronize), 4)
+        # the same step captured once into a HIP graph and replayed (the eager step is launch-bound)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph_obj = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph_obj):
+            step()
+        res[name + "_gpu_graph_ms"] = round(timed(graph_obj.replay, 50, torch.cuda.synchronize), 4)
+    # CPU restatement of the dense path
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    lp = [{k: v.detach().cpu().requires_grad_(True) for k, v in m.named_parameters()} for m in store.layers]
+    xc, bc = x.cpu(), bias.cpu()
+
+    def cpu_step():
+        out = ref_torch.inference_dense(xc, lp, bc)
+        out.sum().backward()
+    res["dense_cpu_port_ms"] = round(timed(cpu_step, 3, lambda: None), 2)
+    res["cpu_threads"] = threads
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (isort: keep above the CDLL call)
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, os.environ.get("GATMI_LIB", "libgatmi.so"))   # GATMI_LIB: diagnostic builds only
+LIB_PATH = os.path.join(_HERE, "libgatmi.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -156,3 +156,46 @@ def test_head_counts_outside_the_fused_shapes_run_in_groups():
     bm[0, dst, src] = 0.0
     dense = m(xt[None], torch.tensor(bm, device=dev), "elu", "concat")
     assert_close(dense[0].detach().cpu().numpy(), out.detach().cpu().numpy(), rtol=2e-6, atol_scale=1e-6, what="6 heads dense")
+
+
+def test_training_step_replays_from_a_hip_graph():
+    """The C ABI only enqueues on the caller's stream and allocates nothing, so a whole
+    forward + backward can be captured once and replayed (small graphs are launch-bound)."""
+    from gat_amd import CSRGraph
+    from gat_amd.layers import GATHeads
+    from tests.util import layer_params
+    dev = torch.device("cuda:0")
+    n, F, H, D = 300, 16, 8, 8
+    dst, src = random_graph(n, 5.0, seed=4, hubs=1, hub_deg=280)
+    g = CSRGraph.from_coo(dst, src, n, dev, chunk=64)
+    m = GATHeads(F, H, D, device=dev)
+    m.load(layer_params(F, H, D, seed=5))
+    x = torch.randn(n, F, device=dev)
+    dout = torch.randn(n, H * D, device=dev)
+    static_out = torch.empty(n, H * D, device=dev)
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        out = m(x, g, "elu", "concat")
+        out.backward(dout)
+        static_out.copy_(out.detach())
+    step()
+    eager = (static_out.clone(), m.W.grad.clone(), m.a1.grad.clone())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    x.copy_(torch.randn(n, F, device=dev))        # new input, then back: replays must track the buffers
+    graph.replay()
+    assert not torch.equal(static_out, eager[0])
+    x.copy_(torch.randn(n, F, device=dev, generator=torch.Generator(device=dev).manual_seed(0)))
+    graph.replay()
+    a = static_out.clone()
+    step()
+    torch.cuda.synchronize()
+    assert torch.equal(a, static_out)
