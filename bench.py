@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--edges", type=int, default=0, help="override edge count per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
+                    help="bf16: gathered tables in bf16 (2e-2 parity class); the headline is f32")
     return ap.parse_args()
 
 
@@ -52,13 +54,15 @@ def layer_alg_bytes(E, N, f_in=F_IN, H=HEADS, D=WIDTH, s=4):
     return E * per_edge + N * per_node
 
 
-def kernel_alg_bytes(name, E, N, H=HEADS, D=WIDTH, f_in=F_IN):
-    """Algorithmic bytes of one launch of each entry point (what the math must touch once)."""
+def kernel_alg_bytes(name, E, N, H=HEADS, D=WIDTH, f_in=F_IN, s=4):
+    """Algorithmic bytes of one launch of each entry point (what the math must touch once);
+    s = bytes per element of the gathered table (4 fp32, 2 bf16)."""
     hd = H * D * 4
+    hg = H * D * s
     if name == "gatmi_gat_fwd":       # gather Wh row + f2 + col id per edge; f1, item, out per node
-        return E * (hd + H * 4 + 4) + N * (hd + H * 4 + 16)
+        return E * (hg + H * 4 + 4) + N * (hd + H * 4 + 16)
     if name == "gatmi_gat_bwd_csc":   # gather g row + {f1,lse,c} + row id per edge; Wh, f2, df1 in, dWh, df2 out per node
-        return E * (hd + 3 * H * 4 + 4) + N * (2 * hd + 3 * H * 4 + 16)
+        return E * (hg + 3 * H * 4 + 4) + N * (2 * hd + 3 * H * 4 + 16)
     if name == "gatmi_gat_bwd_node":  # dOut, out, agg, pos in; g out; small per-head vectors
         return N * (5 * hd + 8 * H * 4)
     if name == "gatmi_proj_fwd":
@@ -162,7 +166,7 @@ def main():
         E_rank = graph.nnz
         x = synth.normal((n_own, F_IN), 5, dev)
         dout = synth.normal((n_own, HEADS * WIDTH), 8, dev)
-        heads = GATHeads(F_IN, HEADS, WIDTH, device=dev)
+        heads = GATHeads(F_IN, HEADS, WIDTH, device=dev, storage=args.storage)
         heads.load(synth.glorot_layer(F_IN, HEADS, WIDTH, 7, dev))
         heads.train()
         params = list(heads.parameters())
@@ -208,25 +212,25 @@ def main():
         dom = max(ksum, key=lambda k: ksum[k][0]) if ksum else None
         roofline = None
         if dom:
-            ab = kernel_alg_bytes(dom, E_rank, n_own)
+            ab = kernel_alg_bytes(dom, E_rank, n_own, s=4 if args.storage == "f32" else 2)
             gbps = ab / (ksum[dom][0] * 1e-3) / 1e9
             traffic, traffic_src = None, None
             try:   # PMC-measured HBM bytes per launch, taken in separate rocprofv3 --pmc runs of this same workload
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                if world == 1 and tj.get("workload_edges") == E_rank:
+                if world == 1 and args.storage == "f32" and tj.get("workload_edges") == E_rank:
                     traffic, traffic_src = tj["kernels"].get(dom), tj.get("source")
             except (OSError, ValueError, KeyError):
                 pass
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "alg_bytes_per_launch": ab, "avg_ms": round(ksum[dom][0], 4)}
-        lb = layer_alg_bytes(E_rank, n_own)
+        lb = layer_alg_bytes(E_rank, n_own, s=4 if args.storage == "f32" else 2)
         lg = lb / (ms_per_step * 1e-3) / 1e9
         line = {
             "metric": "GAT layer fwd+bwd edges/sec (8 heads) + % HBM roofline at 1/2/4/8 GPUs",
             "value": E_total / (ms_per_step * 1e-3), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.storage == "f32" else "f32 arithmetic, bf16 gather tables", "data": "synthetic",
             "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
             "config": {"workload": "R-MAT power-law graph at ogbn-products shape per GPU: %d nodes, %d edge entries "
                                    "(self-loops included), %d-d features, %d heads x %d, ELU, fwd+bwd of one layer"

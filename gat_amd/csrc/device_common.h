@@ -56,6 +56,26 @@ __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x)
 // derivative of ELU written in terms of its OUTPUT y: 1 for y > 0, y + 1 (= exp(x)) otherwise
 __device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
 
+// bf16 storage of gathered tables: two values per dword, element 0 in the low half.
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 r = __builtin_convertvector((f32x2){a, b}, bf16x2);   // v_cvt_pk_bf16_f32, round to nearest even
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// Four consecutive elements c0..c0+3 of row `row` of a [rows, hd] table stored as fp32 or bf16.
+template <bool BF16>
+__device__ __forceinline__ float4 load_row4(const void *base, int64_t row, int hd, int c0) {
+    if constexpr (BF16) {
+        const uint2 u = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(base) + row * hd + c0);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    } else {
+        return *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(base) + row * hd + c0);
+    }
+}
+
 // Fixed-order column sum of per-block partial results.  Launch with dim3(64, 16) threads: thread
 // (cx, ry) adds rows ry, ry+16, ... of its column, the 16 partial sums meet in LDS and row 0 adds
 // them in order, so the result does not depend on scheduling.  `load(r)` returns row r's value.

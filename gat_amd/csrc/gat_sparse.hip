@@ -33,7 +33,8 @@ struct FwdArgs {
     const int4 *items;
     int64_t n_items;
     const int32_t *col;
-    const float *feat, *f1, *f2, *bias, *resid;
+    const void *feat;          // gathered source rows, fp32 or bf16 (template parameter BF16)
+    const float *f1, *f2, *bias, *resid;
     float *out, *agg, *pos, *lse, *q, *ws;
     int activation, reduce;
     float slope, coef_keep, feat_keep;
@@ -53,7 +54,7 @@ struct RowState {
 };
 
 // One batch of U neighbours of one row group.
-template <int G, int LPH, int U, bool SAVE, bool DROP>
+template <int G, int LPH, int U, bool SAVE, bool DROP, bool BF16>
 __device__ __forceinline__ void fwd_batch(RowState &st, const FwdArgs &a, const int32_t *cp, int64_t epos,
                                           float f1v, int sub, int head) {
     constexpr int H = G / LPH;
@@ -66,7 +67,7 @@ __device__ __forceinline__ void fwd_batch(RowState &st, const FwdArgs &a, const 
 #pragma unroll
     for (int t = 0; t < U; ++t) {
         z[t] = f1v + a.f2[(int64_t)j[t] * H + head];
-        v[t] = *reinterpret_cast<const float4 *>(a.feat + (int64_t)j[t] * HD + sub * 4);
+        v[t] = load_row4<BF16>(a.feat, j[t], HD, sub * 4);
     }
     float e[U];
     float mn = st.m;
@@ -146,7 +147,7 @@ __device__ __forceinline__ void fwd_finish(const RowState &st, const FwdArgs &a,
     *reinterpret_cast<float4 *>(a.out + row * HD + sub * 4) = r;
 }
 
-template <int G, int LPH, bool SAVE, bool DROP>
+template <int G, int LPH, bool SAVE, bool DROP, bool BF16>
 __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
     constexpr int RPW = 64 / G;
     constexpr int H = G / LPH;
@@ -169,12 +170,12 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
     st.acc = make_float4(0.f, 0.f, 0.f, 0.f);
     st.pos = make_float4(0.f, 0.f, 0.f, 0.f);
     int k = 0;
-    for (; k + 4 <= len; k += 4) fwd_batch<G, LPH, 4, SAVE, DROP>(st, a, cp + k, (int64_t)item.y + k, f1v, sub, head);
+    for (; k + 4 <= len; k += 4) fwd_batch<G, LPH, 4, SAVE, DROP, BF16>(st, a, cp + k, (int64_t)item.y + k, f1v, sub, head);
     if (k + 2 <= len) {
-        fwd_batch<G, LPH, 2, SAVE, DROP>(st, a, cp + k, (int64_t)item.y + k, f1v, sub, head);
+        fwd_batch<G, LPH, 2, SAVE, DROP, BF16>(st, a, cp + k, (int64_t)item.y + k, f1v, sub, head);
         k += 2;
     }
-    if (k < len) fwd_batch<G, LPH, 1, SAVE, DROP>(st, a, cp + k, (int64_t)item.y + k, f1v, sub, head);
+    if (k < len) fwd_batch<G, LPH, 1, SAVE, DROP, BF16>(st, a, cp + k, (int64_t)item.y + k, f1v, sub, head);
 
     if (item.w < 0) {
         fwd_finish<G, LPH, SAVE>(st, a, row, sub, head);
@@ -232,6 +233,7 @@ struct BwdNodeArgs {
     int64_t n;
     const float *dout, *out, *agg, *pos, *q, *f1, *lse;
     float *g, *stats, *df1, *ws;
+    uint32_t *g16;             // optional bf16 copy of g (two values per dword), the table the per-source kernel gathers
     int activation, reduce;
     float slope;
 };
@@ -267,7 +269,8 @@ __global__ __launch_bounds__(256) void gat_bwd_node_kernel(BwdNodeArgs a) {
         const float4 ps = *reinterpret_cast<const float4 *>(a.pos + row * HD + sub * 4);
         const float c = group_sum<LPH>(dot4(gv, ag));
         const float gp = group_sum<LPH>(dot4(gv, ps));
-        *reinterpret_cast<float4 *>(a.g + row * HD + sub * 4) = gv;
+        if (a.g) *reinterpret_cast<float4 *>(a.g + row * HD + sub * 4) = gv;
+        if (a.g16) *reinterpret_cast<uint2 *>(a.g16 + (row * HD + sub * 4) / 2) = make_uint2(pack_bf16x2(gv.x, gv.y), pack_bf16x2(gv.z, gv.w));
         if (sub % LPH == 0) {
             const float qv = a.q[row * H + head];
             a.stats[row * 3 * H + head] = a.f1[row * H + head];
@@ -302,7 +305,8 @@ struct BwdCscArgs {
     const int4 *items;
     int64_t n_items;
     const int32_t *rowidx, *perm;
-    const float *g, *stats, *feat, *f2, *df1, *a1, *a2;
+    const void *g;             // gathered destination rows of g, fp32 or bf16 (template parameter BF16)
+    const float *stats, *feat, *f2, *df1, *a1, *a2;
     float *dfeat, *df2, *ws;
     float slope, coef_keep, feat_keep;
     uint64_t seed;
@@ -313,7 +317,7 @@ struct SrcState {
     float df2;
 };
 
-template <int G, int LPH, int U, bool DROP>
+template <int G, int LPH, int U, bool DROP, bool BF16>
 __device__ __forceinline__ void bwd_batch(SrcState &st, const BwdCscArgs &a, const int32_t *rp, int64_t cpos,
                                           float f2v, float4 whj, int sub, int head) {
     constexpr int H = G / LPH;
@@ -325,7 +329,7 @@ __device__ __forceinline__ void bwd_batch(SrcState &st, const BwdCscArgs &a, con
     for (int t = 0; t < U; ++t) i[t] = rp[t];
 #pragma unroll
     for (int t = 0; t < U; ++t) {
-        gv[t] = *reinterpret_cast<const float4 *>(a.g + (int64_t)i[t] * HD + sub * 4);
+        gv[t] = load_row4<BF16>(a.g, i[t], HD, sub * 4);
         const float *s = a.stats + (int64_t)i[t] * 3 * H + head;
         f1v[t] = s[0];
         lsev[t] = s[H];
@@ -372,7 +376,7 @@ __device__ __forceinline__ void bwd_finish(const SrcState &st, const BwdCscArgs 
     if (sub % LPH == 0) a.df2[j * H + head] = st.df2;
 }
 
-template <int G, int LPH, bool DROP>
+template <int G, int LPH, bool DROP, bool BF16>
 __global__ __launch_bounds__(256) void gat_bwd_csc_kernel(BwdCscArgs a) {
     constexpr int RPW = 64 / G;
     constexpr int H = G / LPH;
@@ -395,12 +399,12 @@ __global__ __launch_bounds__(256) void gat_bwd_csc_kernel(BwdCscArgs a) {
     st.acc = make_float4(0.f, 0.f, 0.f, 0.f);
     st.df2 = 0.f;
     int k = 0;
-    for (; k + 4 <= len; k += 4) bwd_batch<G, LPH, 4, DROP>(st, a, rp + k, (int64_t)item.y + k, f2v, whj, sub, head);
+    for (; k + 4 <= len; k += 4) bwd_batch<G, LPH, 4, DROP, BF16>(st, a, rp + k, (int64_t)item.y + k, f2v, whj, sub, head);
     if (k + 2 <= len) {
-        bwd_batch<G, LPH, 2, DROP>(st, a, rp + k, (int64_t)item.y + k, f2v, whj, sub, head);
+        bwd_batch<G, LPH, 2, DROP, BF16>(st, a, rp + k, (int64_t)item.y + k, f2v, whj, sub, head);
         k += 2;
     }
-    if (k < len) bwd_batch<G, LPH, 1, DROP>(st, a, rp + k, (int64_t)item.y + k, f2v, whj, sub, head);
+    if (k < len) bwd_batch<G, LPH, 1, DROP, BF16>(st, a, rp + k, (int64_t)item.y + k, f2v, whj, sub, head);
     if (item.w < 0) {
         bwd_finish<G, LPH, DROP>(st, a, j, sub, head);
     } else {
@@ -468,13 +472,15 @@ static inline unsigned blocks_for(int64_t n_groups, int G) {
     X(64, 2) X(64, 4) X(64, 8) X(64, 16) X(64, 32) X(64, 64)
 
 template <int G, int LPH>
-static int launch_fwd(const FwdArgs &a, const int4 *split, int64_t n_split, bool save, bool drop, hipStream_t st) {
+static int launch_fwd(const FwdArgs &a, const int4 *split, int64_t n_split, bool save, bool drop, bool bf16, hipStream_t st) {
     const unsigned nb = blocks_for(a.n_items, G);
     if (nb) {
-        if (save && drop) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, true, true>), dim3(nb), dim3(256), 0, st, a);
-        else if (save) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, true, false>), dim3(nb), dim3(256), 0, st, a);
-        else if (drop) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, false, true>), dim3(nb), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, false, false>), dim3(nb), dim3(256), 0, st, a);
+        if (bf16 && save) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, true, false, true>), dim3(nb), dim3(256), 0, st, a);
+        else if (bf16) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, false, false, true>), dim3(nb), dim3(256), 0, st, a);
+        else if (save && drop) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, true, true, false>), dim3(nb), dim3(256), 0, st, a);
+        else if (save) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, true, false, false>), dim3(nb), dim3(256), 0, st, a);
+        else if (drop) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, false, true, false>), dim3(nb), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, false, false, false>), dim3(nb), dim3(256), 0, st, a);
         GATMI_LAUNCH_CHECK("gat_fwd");
     }
     if (n_split > 0) {
@@ -501,11 +507,12 @@ static int launch_bwd_node(const BwdNodeArgs &a, float *dbias, hipStream_t st) {
 }
 
 template <int G, int LPH>
-static int launch_bwd_csc(const BwdCscArgs &a, const int4 *split, int64_t n_split, bool drop, hipStream_t st) {
+static int launch_bwd_csc(const BwdCscArgs &a, const int4 *split, int64_t n_split, bool drop, bool bf16, hipStream_t st) {
     const unsigned nb = blocks_for(a.n_items, G);
     if (nb) {
-        if (drop) hipLaunchKernelGGL((gat_bwd_csc_kernel<G, LPH, true>), dim3(nb), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gat_bwd_csc_kernel<G, LPH, false>), dim3(nb), dim3(256), 0, st, a);
+        if (bf16) hipLaunchKernelGGL((gat_bwd_csc_kernel<G, LPH, false, true>), dim3(nb), dim3(256), 0, st, a);
+        else if (drop) hipLaunchKernelGGL((gat_bwd_csc_kernel<G, LPH, true, false>), dim3(nb), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gat_bwd_csc_kernel<G, LPH, false, false>), dim3(nb), dim3(256), 0, st, a);
         GATMI_LAUNCH_CHECK("gat_bwd_csc");
     }
     if (n_split > 0) {
@@ -547,6 +554,28 @@ extern "C" int gatmi_gat_bwd_finalize(int64_t n, int32_t H, int32_t dp, const fl
     return fail(GATMI_EUNSUPPORTED, "gat_bwd_finalize: no kernel for H=%d dp=%d", H, dp);
 }
 
+namespace gatmi {
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float4 *src, int64_t n4, uint2 *dst) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        const float4 v = src[e];
+        dst[e] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+}
+}  // namespace gatmi
+
+extern "C" int gatmi_to_bf16(const float *src, int64_t n_elems, uint16_t *dst, void *stream) {
+    GATMI_REQUIRE(n_elems >= 0 && n_elems % 4 == 0, GATMI_EINVAL, "to_bf16: element count %lld must be a non-negative multiple of 4", (long long)n_elems);
+    if (n_elems == 0) return GATMI_OK;
+    GATMI_REQUIRE(src && dst, GATMI_EINVAL, "to_bf16: null pointer");
+    GATMI_REQUIRE_ALIGNED(src); GATMI_REQUIRE_ALIGNED(dst);
+    const int64_t n4 = n_elems / 4;
+    const unsigned nb = (unsigned)std::min<int64_t>(8192, (n4 + 255) / 256);
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4 *>(src), n4, reinterpret_cast<uint2 *>(dst));
+    GATMI_LAUNCH_CHECK("to_bf16");
+    return GATMI_OK;
+}
+
 extern "C" size_t gatmi_gat_fwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp) {
     if (n_slots <= 0) return 0;
     return (size_t)n_slots * (size_t)(3 * H + 2 * H * dp);
@@ -554,7 +583,7 @@ extern "C" size_t gatmi_gat_fwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp
 
 extern "C" int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
                              const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
-                             const int32_t *col, const float *feat, const float *f1, const float *f2,
+                             const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
                              const float *bias, const float *resid, int32_t activation, int32_t reduce,
                              float slope, float coef_keep, float feat_keep, uint64_t seed,
                              float *out, float *agg, float *pos, float *lse, float *q,
@@ -583,9 +612,12 @@ extern "C" int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
     a.activation = activation; a.reduce = reduce;
     a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
     const bool drop = coef_keep < 1.f || feat_keep < 1.f;
+    GATMI_REQUIRE(feat_dtype == GATMI_DTYPE_F32 || feat_dtype == GATMI_DTYPE_BF16, GATMI_EUNSUPPORTED, "gat_fwd: feat_dtype %d", feat_dtype);
+    const bool bf16 = feat_dtype == GATMI_DTYPE_BF16;
+    GATMI_REQUIRE(!(bf16 && drop), GATMI_EUNSUPPORTED, "gat_fwd: dropout is only built for fp32 source rows");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int4 *sp = reinterpret_cast<const int4 *>(split);
-#define X(g, l) if (G == g && LPH == l) return launch_fwd<g, l>(a, sp, n_split, save, drop, st);
+#define X(g, l) if (G == g && LPH == l) return launch_fwd<g, l>(a, sp, n_split, save, drop, bf16, st);
     GATMI_FOR_SHAPES(X)
 #undef X
     return fail(GATMI_EUNSUPPORTED, "gat_fwd: no kernel for H=%d dp=%d", H, dp);
@@ -597,19 +629,20 @@ extern "C" int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
                                   const float *dout, const float *out, const float *agg, const float *pos,
                                   const float *q, const float *f1, const float *lse,
                                   int32_t activation, int32_t reduce, float slope,
-                                  float *g, float *stats, float *df1, float *dbias, float *ws, void *stream) {
+                                  float *g, uint16_t *g16, float *stats, float *df1, float *dbias, float *ws, void *stream) {
     int G, LPH;
     int rc = check_shape(H, dp, &G, &LPH);
     if (rc) return rc;
     GATMI_REQUIRE(n_dst >= 0, GATMI_EINVAL, "gat_bwd_node: negative size");
-    GATMI_REQUIRE(dout && agg && pos && q && f1 && lse && g && stats && df1 && ws, GATMI_EINVAL, "gat_bwd_node: null pointer");
+    GATMI_REQUIRE(dout && agg && pos && q && f1 && lse && (g || g16) && stats && df1 && ws, GATMI_EINVAL, "gat_bwd_node: null pointer");
+    GATMI_REQUIRE_ALIGNED(g16);
     GATMI_REQUIRE(activation == GATMI_ACT_IDENTITY || (activation == GATMI_ACT_ELU && out), GATMI_EUNSUPPORTED, "gat_bwd_node: activation %d (ELU needs `out`)", activation);
     GATMI_REQUIRE(reduce == GATMI_REDUCE_CONCAT || (reduce == GATMI_REDUCE_MEAN && activation == GATMI_ACT_IDENTITY), GATMI_EUNSUPPORTED, "gat_bwd_node: reduce %d", reduce);
     GATMI_REQUIRE_ALIGNED(dout); GATMI_REQUIRE_ALIGNED(out); GATMI_REQUIRE_ALIGNED(agg); GATMI_REQUIRE_ALIGNED(pos);
     GATMI_REQUIRE_ALIGNED(g); GATMI_REQUIRE_ALIGNED(ws);
     BwdNodeArgs a;
     a.n = n_dst; a.dout = dout; a.out = out; a.agg = agg; a.pos = pos; a.q = q; a.f1 = f1; a.lse = lse;
-    a.g = g; a.stats = stats; a.df1 = df1; a.ws = ws;
+    a.g = g; a.g16 = reinterpret_cast<uint32_t *>(g16); a.stats = stats; a.df1 = df1; a.ws = ws;
     a.activation = activation; a.reduce = reduce; a.slope = slope;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X(gg, l) if (G == gg && LPH == l) return launch_bwd_node<gg, l>(a, dbias, st);
@@ -626,7 +659,7 @@ extern "C" size_t gatmi_gat_bwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp
 extern "C" int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
                                  const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                                  const int32_t *rowidx, const int32_t *perm,
-                                 const float *g, const float *stats, const float *feat, const float *f2,
+                                 const void *g, int32_t g_dtype, const float *stats, const float *feat, const float *f2,
                                  const float *df1, const float *a1, const float *a2,
                                  float slope, float coef_keep, float feat_keep, uint64_t seed,
                                  float *dfeat, float *df2, float *ws, void *stream) {
@@ -650,9 +683,12 @@ extern "C" int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
     a.dfeat = dfeat; a.df2 = df2; a.ws = ws;
     a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
     const bool drop = coef_keep < 1.f || feat_keep < 1.f;
+    GATMI_REQUIRE(g_dtype == GATMI_DTYPE_F32 || g_dtype == GATMI_DTYPE_BF16, GATMI_EUNSUPPORTED, "gat_bwd_csc: g_dtype %d", g_dtype);
+    const bool bf16 = g_dtype == GATMI_DTYPE_BF16;
+    GATMI_REQUIRE(!(bf16 && drop), GATMI_EUNSUPPORTED, "gat_bwd_csc: dropout is only built for fp32 rows");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int4 *sp = reinterpret_cast<const int4 *>(split);
-#define X(gg, l) if (G == gg && LPH == l) return launch_bwd_csc<gg, l>(a, sp, n_split, drop, st);
+#define X(gg, l) if (G == gg && LPH == l) return launch_bwd_csc<gg, l>(a, sp, n_split, drop, bf16, st);
     GATMI_FOR_SHAPES(X)
 #undef X
     return fail(GATMI_EUNSUPPORTED, "gat_bwd_csc: no kernel for H=%d dp=%d", H, dp);

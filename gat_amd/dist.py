@@ -210,7 +210,7 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             ws = ops._new((_lib.lib.gatmi_gat_fwd_ws_floats(graph.n_slots_csr, H, dp),), x)
         _lib.call("gatmi_gat_fwd", n, H, dp, ptr(graph.items_csr), len(graph.items_csr),
                   ptr(graph.split_csr) if len(graph.split_csr) else None, len(graph.split_csr),
-                  ptr(graph.col), ptr(feat), ptr(f1), ptr(f2), ptr(biasp), None,
+                  ptr(graph.col), ptr(feat), _lib.DTYPE_F32, ptr(f1), ptr(f2), ptr(biasp), None,
                   ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
                   ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
         if need_grad:
@@ -239,7 +239,7 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         dbias = ops._new((hd,), x)
         ws = ops._new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x)
         _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out), ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse),
-                  ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, ptr(g), ptr(stats), ptr(df1), ptr(dbias), ptr(ws), st)
+                  ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, ptr(g), None, ptr(stats), ptr(df1), ptr(dbias), ptr(ws), st)
         dfeat = ops._new((n_src, hd), x)
         df2 = ops._new((n_src, H), x)
         ws2 = None
@@ -247,7 +247,7 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             ws2 = ops._new((_lib.lib.gatmi_gat_bwd_ws_floats(graph.n_slots_csc, H, dp),), x)
         _lib.call("gatmi_gat_bwd_csc", n_src, H, dp, ptr(graph.items_csc), len(graph.items_csc),
                   ptr(graph.split_csc) if len(graph.split_csc) else None, len(graph.split_csc),
-                  ptr(graph.rowidx), ptr(graph.perm), ptr(g), ptr(stats), ptr(feat), ptr(f2), None, None, None,
+                  ptr(graph.rowidx), ptr(graph.perm), ptr(g), _lib.DTYPE_F32, ptr(stats), ptr(feat), ptr(f2), None, None, None,
                   cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dfeat), ptr(df2), ptr(ws2), st)
         ex.scatter_add_halo(dfeat, hd)
         ex.scatter_add_halo(df2, H)

@@ -43,9 +43,10 @@ class GATHeads(nn.Module):
     a1/a2 [H,D], b1/b2 [H] <- the two conv1d(seq_fts, 1, 1); bias [H,D] <- bias_add;
     W_res/b_res <- the residual conv1d (layers.py:30), present only when residual and F != D."""
 
-    def __init__(self, f_in, heads, width, residual=False, device=None):
+    def __init__(self, f_in, heads, width, residual=False, device=None, storage="f32"):
         super().__init__()
         self.f_in, self.heads, self.width = int(f_in), int(heads), int(width)
+        self.storage = storage      # "bf16": gathered tables of the CSR path in bf16 (2e-2 class)
         kw = {"device": device, "dtype": torch.float32}
         self.W = nn.Parameter(torch.empty(f_in, heads, width, **kw))
         self.a1 = nn.Parameter(torch.empty(heads, width, **kw))
@@ -108,7 +109,7 @@ class GATHeads(nn.Module):
         wr = (self.W_res[:, hs] if hn != self.heads else self.W_res) if self.has_res else None
         br = sl(self.b_res) if self.has_res else None
         if isinstance(graph_or_bias, CSRGraph):
-            cfg = ops.make_cfg(hn, D, act, reduce, coef_drop, in_drop, training, seed)
+            cfg = ops.make_cfg(hn, D, act, reduce, coef_drop, in_drop, training, seed, storage=self.storage)
             return ops.sparse_gat_layer(seq, W, sl(self.a1), sl(self.a2), sl(self.b1), sl(self.b2), sl(self.bias),
                                         graph_or_bias, cfg, wr, br)
         cfg = ops.make_cfg(hn, D, act, "concat", coef_drop, in_drop, training, seed)

@@ -47,6 +47,9 @@ extern "C" {
 #define GATMI_ACT_IDENTITY 0    /* `lambda x: x`, models/sp_gat.py:30 */
 #define GATMI_ACT_ELU      1    /* tf.nn.elu,     models/sp_gat.py:9  */
 
+#define GATMI_DTYPE_F32  0      /* storage of a gathered table: fp32 rows ...                      */
+#define GATMI_DTYPE_BF16 1      /* ... or bf16 rows (half the gather traffic; arithmetic stays fp32) */
+
 #define GATMI_REDUCE_CONCAT 0   /* tf.concat(attns, -1), models/sp_gat.py:17 */
 #define GATMI_REDUCE_MEAN   1   /* tf.add_n(out) / n,    models/sp_gat.py:32 (identity activation only) */
 
@@ -136,7 +139,8 @@ int gatmi_proj_bwd_input(const float *dWh, int64_t n, int32_t f_in, const float 
  * :24 (coefs . seq_fts), :25 (bias_add), :30 (residual add), :34 (activation) and the head
  * concat / mean of models/sp_gat.py:17,32 — for all H heads.
  *   items/n_items, split/n_split : gatmi_work_items of the CSR rowptr; col: CSR source ids
- *   feat [n_src, hd] gathered rows (Wh); f1 [n_dst, H]; f2 [n_src, H]
+ *   feat [n_src, hd] gathered rows (Wh) stored as feat_dtype (GATMI_DTYPE_F32, or GATMI_DTYPE_BF16
+ *       written by gatmi_to_bf16: dropout must then be off); f1 [n_dst, H]; f2 [n_src, H]
  *   bias [hd] or NULL; resid [n_dst, hd] or NULL (added before the activation)
  *   out [n_dst, hd] (concat) or [n_dst, dp] (mean)
  *   agg, pos [n_dst, hd], lse, q [n_dst, H]: saved for the backward pass, all NULL for inference
@@ -148,14 +152,15 @@ int gatmi_proj_bwd_input(const float *dWh, int64_t n, int32_t f_in, const float 
 size_t gatmi_gat_fwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp);
 int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
                   const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
-                  const int32_t *col, const float *feat, const float *f1, const float *f2,
+                  const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
                   const float *bias, const float *resid, int32_t activation, int32_t reduce,
                   float slope, float coef_keep, float feat_keep, uint64_t seed,
                   float *out, float *agg, float *pos, float *lse, float *q,
                   float *ws, void *stream);
 
 /* Backward, per-destination part (no gather).  From dOut and the saved forward tensors:
- *   g [n_dst, hd]    = dOut * activation'(out)              (dOut / H per head for mean)
+ *   g [n_dst, hd]    = dOut * activation'(out)              (dOut / H per head for mean);
+ *       g16: the same rows in bf16 for gatmi_gat_bwd_csc's gather; either of g / g16 may be NULL
  *   stats [n_dst, 3, H] = {f1, lse, c}, c = <g, agg> per head
  *   df1 [n_dst, H]   = (1 - slope) * (<g, pos> - c * q)     = sum_j dlogit_ij  (gradient of f_1)
  *   dbias [hd]       = sum_i g (NULL to skip);  dresid is g itself.
@@ -165,7 +170,7 @@ int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
                        const float *dout, const float *out, const float *agg, const float *pos,
                        const float *q, const float *f1, const float *lse,
                        int32_t activation, int32_t reduce, float slope,
-                       float *g, float *stats, float *df1, float *dbias, float *ws, void *stream);
+                       float *g, uint16_t *g16, float *stats, float *df1, float *dbias, float *ws, void *stream);
 
 /* Backward, per-source part: transposed SpMM + SDDMM over the CSC structure.
  *   items/split: gatmi_work_items of colptr; rowidx: CSC destination ids; perm: CSR position of
@@ -177,10 +182,14 @@ size_t gatmi_gat_bwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp);
 int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
                       const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                       const int32_t *rowidx, const int32_t *perm,
-                      const float *g, const float *stats, const float *feat, const float *f2,
+                      const void *g, int32_t g_dtype, const float *stats, const float *feat, const float *f2,
                       const float *df1, const float *a1, const float *a2,
                       float slope, float coef_keep, float feat_keep, uint64_t seed,
                       float *dfeat, float *df2, float *ws, void *stream);
+
+/* fp32 -> bf16 (round to nearest even) copy of a table, n_elems a multiple of 4: the gather-side
+ * storage for GATMI_DTYPE_BF16. */
+int gatmi_to_bf16(const float *src, int64_t n_elems, uint16_t *dst, void *stream);
 
 /* Last step of the backward pass for owned rows when gatmi_gat_bwd_csc ran with a1 == NULL
  * (row-partitioned runs add the peers' halo contributions to dfeat / df2 first):

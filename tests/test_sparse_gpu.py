@@ -150,3 +150,34 @@ def test_known_answers():
     o1 = ops.sparse_gat_layer(torch.tensor(x[:1], device=dev), torch.tensor(W, device=dev),
                               torch.ones(H, D, device=dev), torch.ones(H, D, device=dev), z(H), z(H), z(H, D), g1, cfg)
     assert_close(o1.cpu().numpy(), wh[:1], what="single node")
+
+
+@pytest.mark.parametrize("H,D,activation,reduce", [(8, 8, "elu", "concat"), (1, 7, "identity", "mean")])
+def test_bf16_gather_tables_stay_within_the_bf16_class(H, D, activation, reduce):
+    """storage="bf16": the gathered Wh rows (forward) and g rows (backward) are kept in bf16,
+    arithmetic stays fp32.  Tolerance: 2e-2 of the tensor's scale against the float64 oracle."""
+    from gat_amd import CSRGraph, ops
+    dev = torch.device("cuda:0")
+    n, F = 400, 24
+    dst, src = random_graph(n, 8.0, seed=3, hubs=2, hub_deg=300)
+    p = layer_params(F, H, D, seed=4)
+    x = np.random.default_rng(5).normal(0, 1, (n, F))
+    tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+    xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
+    graph = CSRGraph.from_coo(dst, src, n, dev, chunk=64)
+    out = ops.sparse_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], graph,
+                               ops.make_cfg(H, D, activation, reduce, storage="bf16"))
+    exact = ops.sparse_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], graph,
+                                 ops.make_cfg(H, D, activation, reduce))
+    assert not torch.equal(out, exact)
+    dout = np.random.default_rng(6).normal(0, 1, tuple(out.shape))
+    out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
+    rowptr, col = ref_numpy.coo_to_csr(np.stack([dst, src], 1), n)
+    rp = _oracle_leaves(p, n)
+    rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = ref_torch.layer_csr(rx, rp, torch.tensor(rowptr), torch.tensor(col), activation, reduce)
+    ref.backward(torch.tensor(dout))
+    assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-2, atol_scale=2e-2, what="bf16 forward")
+    assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), rtol=2e-2, atol_scale=2e-2, what="bf16 dX")
+    for k in ("W", "a1", "a2", "bias"):
+        assert_close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), rtol=2e-2, atol_scale=2e-2, what="bf16 d" + k)
