@@ -158,7 +158,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-        layer_step, E_rank, info = gdist.build_bench_step(rank, world, n_own, e_own, F_IN, HEADS, WIDTH, dev, chunk)
+        layer_step, E_rank, info = gdist.build_bench_step(rank, world, n_own, e_own, F_IN, HEADS, WIDTH, dev, chunk, args.storage)
     else:
         dst, src = synth.rmat_graph(n_own, e_own, 4, dev)
         graph = CSRGraph.from_device_coo(dst, src, n_own, n_own, chunk=chunk)

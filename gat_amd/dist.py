@@ -196,7 +196,17 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         f1 = ops._new((n, H), x)
         _lib.call("gatmi_proj_fwd", ptr(x), n, F, x.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1.contiguous()),
                   ptr(b2.contiguous()), H, dp, ptr(feat), ptr(f1), ptr(f2), None, None, None, st)
-        ex.gather_halo(feat, hd)
+        bf16 = cfg.storage == "bf16"
+        gtab, gdt = feat, _lib.DTYPE_F32
+        if bf16:
+            # bf16 mode: the gathered table and therefore the halo rows on the wire are bf16 (half the
+            # forward exchange); the owned fp32 rows stay for the parameter gradients
+            gtab, gdt = torch.empty((n_src, hd), dtype=torch.bfloat16, device=x.device), _lib.DTYPE_BF16
+            _lib.call("gatmi_to_bf16", ptr(feat), n * hd, ptr(gtab), st)
+            ex.gather_halo(gtab.view(torch.float32), hd // 2)
+            feat[n:].copy_(gtab[n:])        # the per-source backward sweep reads its own Wh row in fp32 (exact widening)
+        else:
+            ex.gather_halo(feat, hd)
         ex.gather_halo(f2, H)
         biasp = None if bias is None else ops._pad_last(bias.reshape(H, D), D, dp).reshape(hd)
         need_grad = any(ctx.needs_input_grad)
@@ -210,7 +220,7 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             ws = ops._new((_lib.lib.gatmi_gat_fwd_ws_floats(graph.n_slots_csr, H, dp),), x)
         _lib.call("gatmi_gat_fwd", n, H, dp, ptr(graph.items_csr), len(graph.items_csr),
                   ptr(graph.split_csr) if len(graph.split_csr) else None, len(graph.split_csr),
-                  ptr(graph.col), ptr(feat), _lib.DTYPE_F32, ptr(f1), ptr(f2), ptr(biasp), None,
+                  ptr(graph.col), ptr(gtab), gdt, ptr(f1), ptr(f2), ptr(biasp), None,
                   ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
                   ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
         if need_grad:
@@ -233,13 +243,15 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             dout = ops._pad_last(dout, D, dp)
         else:
             dout = ops._pad_last(dout.reshape(n, H, D), D, dp).reshape(n, hd)
-        g = ops._new((n, hd), x)
+        bf16 = cfg.storage == "bf16"
+        g = None if bf16 else ops._new((n, hd), x)
+        g16 = torch.empty((n, hd), dtype=torch.bfloat16, device=x.device) if bf16 else None
         stats = ops._new((n, 3 * H), x)
         df1 = ops._new((n, H), x)
         dbias = ops._new((hd,), x)
         ws = ops._new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x)
         _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out), ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse),
-                  ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, ptr(g), None, ptr(stats), ptr(df1), ptr(dbias), ptr(ws), st)
+                  ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, ptr(g), ptr(g16), ptr(stats), ptr(df1), ptr(dbias), ptr(ws), st)
         dfeat = ops._new((n_src, hd), x)
         df2 = ops._new((n_src, H), x)
         ws2 = None
@@ -247,7 +259,8 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             ws2 = ops._new((_lib.lib.gatmi_gat_bwd_ws_floats(graph.n_slots_csc, H, dp),), x)
         _lib.call("gatmi_gat_bwd_csc", n_src, H, dp, ptr(graph.items_csc), len(graph.items_csc),
                   ptr(graph.split_csc) if len(graph.split_csc) else None, len(graph.split_csc),
-                  ptr(graph.rowidx), ptr(graph.perm), ptr(g), _lib.DTYPE_F32, ptr(stats), ptr(feat), ptr(f2), None, None, None,
+                  ptr(graph.rowidx), ptr(graph.perm), ptr(g16 if bf16 else g), _lib.DTYPE_BF16 if bf16 else _lib.DTYPE_F32,
+                  ptr(stats), ptr(feat), ptr(f2), None, None, None,
                   cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dfeat), ptr(df2), ptr(ws2), st)
         ex.scatter_add_halo(dfeat, hd)
         ex.scatter_add_halo(df2, H)
@@ -280,7 +293,7 @@ def allreduce_grads(params, group=None):
         off += g.numel()
 
 
-def build_bench_step(rank, world, n_own, e_own, f_in, heads, width, device, chunk=DEFAULT_CHUNK):
+def build_bench_step(rank, world, n_own, e_own, f_in, heads, width, device, chunk=DEFAULT_CHUNK, storage="f32"):
     """bench.py's N > 1 workload: every rank owns n_own destination rows of an R-MAT graph with
     world * n_own nodes and generates its own e_own in-edges (sources over the whole id range)."""
     from . import synth
@@ -296,7 +309,7 @@ def build_bench_step(rank, world, n_own, e_own, f_in, heads, width, device, chun
     m.load(synth.glorot_layer(f_in, heads, width, 7, device))
     m.train()
     params = list(m.parameters())
-    cfg = ops.make_cfg(heads, width, "elu", "concat")
+    cfg = ops.make_cfg(heads, width, "elu", "concat", storage=storage)
 
     def step():
         for p in params:

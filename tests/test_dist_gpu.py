@@ -52,6 +52,15 @@ def _worker(rank, world, port, q):
         assert_close(xd.grad.cpu().numpy(), xs.grad.cpu().numpy()[lo:hi], rtol=1e-5, atol_scale=2e-6, what="dX")
         for k in p:
             assert_close(dp_[k].grad.cpu().numpy(), tp[k].grad.cpu().numpy(), rtol=1e-5, atol_scale=5e-6, what="d" + k)
+        # bf16 storage: bf16 rows on the wire, same result class as the single-GPU bf16 layer
+        cfg16 = ops.make_cfg(H, D, "elu", "concat", storage="bf16")
+        b_ = leaves()
+        xb = torch.tensor(x[lo:hi], device=dev, requires_grad=True)
+        o16 = gdist.dist_sparse_gat_layer(xb, b_["W"], b_["a1"], b_["a2"], b_["b1"], b_["b2"], b_["bias"], pg, cfg16)
+        o16.backward(torch.tensor(dout[lo:hi], device=dev))
+        gdist.allreduce_grads(list(b_.values()))
+        assert_close(o16.detach().cpu().numpy(), ref.detach().cpu().numpy()[lo:hi], rtol=2e-2, atol_scale=2e-2, what="bf16 out")
+        assert_close(b_["W"].grad.cpu().numpy(), tp["W"].grad.cpu().numpy(), rtol=2e-2, atol_scale=2e-2, what="bf16 dW")
         # the device-side planner gives the same shard
         e0, e1 = int(rowptr[lo]), int(rowptr[hi])
         dl = torch.tensor(np.repeat(np.arange(lo, hi), np.diff(rowptr[lo:hi + 1])), dtype=torch.int64, device=dev)
