@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--edges", type=int, default=0, help="override edge count per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--workload", choices=["products", "cora"], default="products",
+                    help="products: the headline (default); cora: the two-layer Cora network, GPU vs the CPU restatement")
     ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
                     help="bf16: gathered tables in bf16 (2e-2 parity class); the headline is f32")
     return ap.parse_args()
@@ -96,7 +98,7 @@ class EventProfiler:
         return out
 
 
-def cpu_baseline(sample_nodes=272_114, sample_edges=6_873_238, iters=2):
+def cpu_baseline(sample_nodes=272_114, sample_edges=6_873_238, iters=5):
     """The CPU restatement (oracle) on an R-MAT sample with the benchmark's average degree."""
     from oracle import ref_torch
     from gat_amd import synth
@@ -127,8 +129,67 @@ def cpu_baseline(sample_nodes=272_114, sample_edges=6_873_238, iters=2):
                       "of utils/layers.py:6-34 on stored edges, best of %d fwd+bwd" % (sample_nodes, E, iters)}
 
 
+def run_cora(args):
+    """BASELINE.json configs[0]/[1]: the two-layer Cora network (2708 nodes, 1433 features, 8 x 8 hidden,
+    7 classes; execute_cora.py:13-22) forward + backward on a Cora-shaped random graph: SpGAT.inference
+    and GAT.inference on the GPU next to the CPU restatement of the dense path (the reference's
+    TensorFlow CPU path cannot run here)."""
+    import numpy as np
+    import scipy.sparse as sp
+    from gat_amd import CSRGraph, layers, preprocess
+    from gat_amd.models import GAT, SpGAT
+    from oracle import ref_torch
+    dev = torch.device("cuda:0")
+    n, f, c = 2708, 1433, 7
+    rng = np.random.RandomState(0)
+    adj = sp.random(n, n, density=0.001, random_state=rng, format="csr")
+    adj = ((adj + adj.T) > 0).astype(np.float64)
+    feats = preprocess.preprocess_features(sp.random(n, f, density=0.0127, random_state=rng, format="csr"))[0]
+    graph = CSRGraph.from_reference_triple(preprocess.preprocess_adj_bias(adj), dev)
+    bias = torch.tensor(preprocess.adj_to_bias(np.asarray(adj.todense())[None], [n], 1), dtype=torch.float32, device=dev)
+    x = torch.tensor(np.asarray(feats)[None], dtype=torch.float32, device=dev)
+    kw = dict(hid_units=[8], n_heads=[8, 1], activation=layers.elu, residual=False)
+
+    def timed(fn, iters, sync):
+        for _ in range(args.warmup):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / iters * 1e3
+    res = {}
+    for name, model, g in (("sparse", SpGAT, graph), ("dense", GAT, bias)):
+        store = layers.VariableStore()
+
+        def step():
+            with layers.variable_scope(store):
+                out = model.inference(x, c, n, False, 0.0, 0.0, bias_mat=g, **kw)
+            for p in store.parameters():
+                p.grad = None
+            out.sum().backward()
+        res[name] = timed(step, args.steps, torch.cuda.synchronize)
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    lp = [{k: v.detach().cpu().requires_grad_(True) for k, v in m.named_parameters()} for m in store.layers]
+    xc, bc = x.cpu(), bias.cpu()
+    cpu_ms = timed(lambda: ref_torch.inference_dense(xc, lp, bc).sum().backward(), 3, lambda: None)
+    print(json.dumps({
+        "metric": "Cora two-layer GAT fwd+bwd steps/sec", "value": 1e3 / res["sparse"], "unit": "steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(res["sparse"], 4), "higher_is_better": True,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Cora-shaped random graph: %d nodes, %d stored entries, %d features, 8x8 + 1x7, SpGAT.inference" % (n, graph.nnz, f)},
+        "dense_ms_per_step": round(res["dense"], 4),
+        "cpu_baseline": {"value": 1e3 / cpu_ms, "unit": "steps/s", "cores": threads, "kind": "port",
+                         "sample": "the same two-layer network through the torch-CPU fp32 restatement of the dense path, mean of 3 fwd+bwd"}}),
+        flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "cora":
+        return run_cora(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Secondary measurement: BASELINE.json configs[0] and configs[1] — the two-layer Cora network
 (2708 nodes, 1433 features, 8 heads x 8 hidden, 7 classes; execute_cora.py:13-22) through
-GAT.inference (dense bias_mat) and SpGAT.inference (sparse adjacency), forward + backward, next
-to the CPU restatement of the dense path (oracle/ref_torch.py, torch-CPU fp32; the reference's
-TensorFlow is not installed).  The graph is the reference's own random stand-in for Cora
-(utils/process.py:98-123 style: symmetric, density 0.002, plus self-loops)."""
+GAT.inference (dense bias_mat) and SpGAT.inference (sparse adjacency), forward + backward, eager
+and replayed from a HIP graph.  The graph is the reference's own random stand-in for Cora
+(utils/process.py:98-123 style: symmetric, density 0.002, plus self-loops).  The CPU figure for the
+same network is printed by `python bench.py --workload cora`."""
 import json
 import os
 import sys
@@ -31,7 +31,6 @@ def timed(fn, iters, sync):
 def main():
     from gat_amd import CSRGraph, layers, preprocess
     from gat_amd.models import GAT, SpGAT
-    from oracle import ref_torch
     dev = torch.device("cuda:0")
     n, f, c = 2708, 1433, 7
     rng = np.random.RandomState(0)
@@ -65,17 +64,6 @@ def main():
         with torch.cuda.graph(graph_obj):
             step()
         res[name + "_gpu_graph_ms"] = round(timed(graph_obj.replay, 50, torch.cuda.synchronize), 4)
-    # CPU restatement of the dense path
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
-    lp = [{k: v.detach().cpu().requires_grad_(True) for k, v in m.named_parameters()} for m in store.layers]
-    xc, bc = x.cpu(), bias.cpu()
-
-    def cpu_step():
-        out = ref_torch.inference_dense(xc, lp, bc)
-        out.sum().backward()
-    res["dense_cpu_port_ms"] = round(timed(cpu_step, 3, lambda: None), 2)
-    res["cpu_threads"] = threads
     print(json.dumps(res))
 
 
