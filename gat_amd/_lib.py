@@ -57,6 +57,8 @@ _SIGNATURES = {
     "gatmi_bnf_attn_fwd": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, c_float, P, P, P, P, P, P]),
     "gatmi_bnf_attn_bwd_ws_floats": (c_size_t, [c_int64, c_int32, c_int32]),
     "gatmi_bnf_attn_bwd": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, P, c_float, P, P, P, P, P, P]),
+    "gatmi_ipd_fwd": (c_int, [c_int64, c_int32, c_int32, P, c_int32, c_float, c_uint64, P, P]),
+    "gatmi_ipd_bwd": (c_int, [c_int64, c_int32, c_int32, P, P, P, c_int32, c_float, c_uint64, P, P]),
     "gatmi_halo_pack": (c_int, [P, P, c_int64, c_int32, P, P]),
     "gatmi_halo_unpack_add": (c_int, [P, P, c_int64, c_int32, P, P]),
 }
@@ -68,7 +70,7 @@ for _name, (_res, _args) in _SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ACT_IDENTITY, ACT_ELU = 0, 1
+ACT_IDENTITY, ACT_ELU, ACT_SIGMOID = 0, 1, 2
 DTYPE_F32, DTYPE_BF16 = 0, 1
 REDUCE_CONCAT, REDUCE_MEAN = 0, 1
 

@@ -1,0 +1,205 @@
+// Inner-product decoder for gfx950: utils/layers.py:307-313.
+//     out[b, i, j] = act( <Zd[b,i,:], Zd[b,j,:]> ),   Zd = dropout(Z),   act = sigmoid (default) or identity
+// The [B, N, N] result is the only large array (the kernel is bound by writing it once); the
+// contraction over the F features runs on v_mfma_f32_16x16x4_f32.  Block (b, 64 destination rows):
+// wave w owns rows 16*w .. 16*w+15, keeps their features as the A operand in registers and walks
+// the graph's rows in LDS-staged chunks as the B operand.
+//
+// Backward: with S = (dOut + dOut^T) . act'(x) (act' = out (1 - out) for the sigmoid, which is
+// symmetric because x is), dZd = S . Zd.  The A operand S[i, j] is built per lane from one direct
+// and one transposed read of dOut and one read of the saved output; Zd chunks are the B operand.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "device_common.h"
+
+namespace gatmi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct IpdArgs {
+    int N, F;
+    const float *Z, *out_saved, *dOut;
+    float *out, *dZ;
+    float keep;
+    uint64_t seed;
+    int activation;
+};
+
+template <int NTF>
+struct IpdShape {
+    static constexpr int FP = 16 * NTF;            // feature columns, zero-padded
+    static constexpr int LD = FP + 4;              // LDS row stride: 4 mod 8 keeps the operand reads spread over the banks
+    static constexpr int KS = FP / 4;              // MFMA k-steps of the forward
+    static constexpr int JC = NTF <= 4 ? 128 : 64; // rows staged per chunk
+};
+
+__device__ __forceinline__ float ipd_load(const IpdArgs &a, int64_t row, int c) {
+    float v = a.Z[row * a.F + c];
+    if (a.keep < 1.f) v = drop_feat1(v, a.seed, row, a.F, c, a.keep);
+    return v;
+}
+
+// rows jc .. jc+JC-1 of graph b into LDS (dropout applied, zero outside the graph / feature range)
+template <int NTF>
+__device__ __forceinline__ void ipd_stage(const IpdArgs &a, int64_t b, int jc, float *zs) {
+    using S = IpdShape<NTF>;
+    for (int e = threadIdx.x; e < S::JC * S::FP; e += 256) {
+        const int r = e / S::FP, c = e % S::FP;
+        float v = 0.f;
+        if (jc + r < a.N && c < a.F) v = ipd_load(a, b * a.N + jc + r, c);
+        zs[r * S::LD + c] = v;
+    }
+}
+
+template <int NTF>
+__global__ __launch_bounds__(256) void ipd_fwd_kernel(IpdArgs a) {
+    using S = IpdShape<NTF>;
+    __shared__ float zs[S::JC * S::LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int N = a.N;
+    const int64_t b = blockIdx.x;
+    const int i0 = blockIdx.y * 64 + wave * 16;
+    const int64_t irow = b * N + min(i0 + m, N - 1);
+    float av[S::KS];
+#pragma unroll
+    for (int s = 0; s < S::KS; ++s) av[s] = (4 * s + kq < a.F) ? ipd_load(a, irow, 4 * s + kq) : 0.f;
+
+    for (int jc = 0; jc < N; jc += S::JC) {
+        __syncthreads();
+        ipd_stage<NTF>(a, b, jc, zs);
+        __syncthreads();
+        if (i0 >= N) continue;
+        const int jend = min(S::JC, N - jc);
+        for (int jt = 0; jt < jend; jt += 16) {
+            f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float *zr = zs + (jt + m) * S::LD + kq;
+#pragma unroll
+            for (int s = 0; s < S::KS; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], zr[4 * s], c, 0, 0, 0);
+            const int j = jc + jt + m;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 4 * kq + r;
+                if (i < N && j < N) {
+                    float v = c[r];
+                    if (a.activation == GATMI_ACT_SIGMOID) v = __builtin_amdgcn_rcpf(1.f + __expf(-v));
+                    a.out[(b * N + i) * (int64_t)N + j] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int NTF>
+__global__ __launch_bounds__(256) void ipd_bwd_kernel(IpdArgs a) {
+    using S = IpdShape<NTF>;
+    __shared__ float zs[S::JC * S::LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int N = a.N;
+    const int64_t b = blockIdx.x;
+    const int i0 = blockIdx.y * 64 + wave * 16;
+    const bool iok = i0 + m < N;
+    const int irow = min(i0 + m, N - 1);
+    const float *grow = a.dOut + (b * N + irow) * (int64_t)N;
+    const float *orow = a.out_saved ? a.out_saved + (b * N + irow) * (int64_t)N : nullptr;
+    const float *gcol = a.dOut + b * N * (int64_t)N + irow;
+    f32x4 acc[NTF];
+#pragma unroll
+    for (int nt = 0; nt < NTF; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int jc = 0; jc < N; jc += S::JC) {
+        __syncthreads();
+        ipd_stage<NTF>(a, b, jc, zs);
+        __syncthreads();
+        if (i0 >= N) continue;
+        const int jend = min(S::JC, N - jc);
+        for (int jt = 0; jt < jend; jt += 16) {
+            float sv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int j = jc + jt + 4 * kq + s;
+                float v = 0.f;
+                if (iok && j < N) {
+                    v = grow[j] + gcol[(int64_t)j * N];
+                    if (orow) { const float o = orow[j]; v *= o * (1.f - o); }
+                }
+                sv[s] = v;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float *zr = zs + (jt + 4 * kq + s) * S::LD + m;
+#pragma unroll
+                for (int nt = 0; nt < NTF; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[s], zr[16 * nt], acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    if (i0 >= N) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * kq + r;
+        if (i >= N) continue;
+#pragma unroll
+        for (int nt = 0; nt < NTF; ++nt) {
+            const int c = 16 * nt + m;
+            if (c < a.F) {
+                float v = acc[nt][r];
+                if (a.keep < 1.f) v = drop_feat1(v, a.seed, b * N + i, a.F, c, a.keep);
+                a.dZ[(b * N + i) * (int64_t)a.F + c] = v;
+            }
+        }
+    }
+}
+
+}  // namespace gatmi
+
+using namespace gatmi;
+
+static int ipd_check(int64_t B, int32_t N, int32_t F, int32_t activation, float keep, const char *name) {
+    GATMI_REQUIRE(B >= 0 && N >= 0 && F >= 1, GATMI_EINVAL, "%s: bad size B=%lld N=%d F=%d", name, (long long)B, N, F);
+    GATMI_REQUIRE(F <= 128, GATMI_EUNSUPPORTED, "%s: feature width %d > 128 not built", name, F);
+    GATMI_REQUIRE(activation == GATMI_ACT_SIGMOID || activation == GATMI_ACT_IDENTITY, GATMI_EUNSUPPORTED,
+                  "%s: activation %d (sigmoid or identity)", name, activation);
+    GATMI_REQUIRE(keep > 0.f && keep <= 1.f, GATMI_EINVAL, "%s: keep probability %g outside (0, 1]", name, keep);
+    GATMI_REQUIRE(B <= 0x7fffffff && (N + 63) / 64 <= 65535, GATMI_ERANGE, "%s: too large for one launch", name);
+    return GATMI_OK;
+}
+
+#define GATMI_IPD_LAUNCH(kernel, name)                                                      \
+    do {                                                                                    \
+        const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64));                            \
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);                             \
+        const int ntf = (F + 15) / 16;                                                      \
+        if (ntf <= 1) hipLaunchKernelGGL((kernel<1>), grid, dim3(256), 0, st, a);           \
+        else if (ntf <= 2) hipLaunchKernelGGL((kernel<2>), grid, dim3(256), 0, st, a);      \
+        else if (ntf <= 4) hipLaunchKernelGGL((kernel<4>), grid, dim3(256), 0, st, a);      \
+        else hipLaunchKernelGGL((kernel<8>), grid, dim3(256), 0, st, a);                    \
+        GATMI_LAUNCH_CHECK(name);                                                           \
+    } while (0)
+
+extern "C" int gatmi_ipd_fwd(int64_t B, int32_t N, int32_t F, const float *Z, int32_t activation,
+                             float keep, uint64_t seed, float *out, void *stream) {
+    int rc = ipd_check(B, N, F, activation, keep, "ipd_fwd");
+    if (rc) return rc;
+    if (B == 0 || N == 0) return GATMI_OK;
+    GATMI_REQUIRE(Z && out, GATMI_EINVAL, "ipd_fwd: null pointer");
+    IpdArgs a = {};
+    a.N = N; a.F = F; a.Z = Z; a.out = out; a.keep = keep; a.seed = seed; a.activation = activation;
+    GATMI_IPD_LAUNCH(ipd_fwd_kernel, "ipd_fwd");
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_ipd_bwd(int64_t B, int32_t N, int32_t F, const float *dOut, const float *out,
+                             const float *Z, int32_t activation, float keep, uint64_t seed, float *dZ, void *stream) {
+    int rc = ipd_check(B, N, F, activation, keep, "ipd_bwd");
+    if (rc) return rc;
+    if (B == 0 || N == 0) return GATMI_OK;
+    GATMI_REQUIRE(dOut && Z && dZ, GATMI_EINVAL, "ipd_bwd: null pointer");
+    GATMI_REQUIRE(activation != GATMI_ACT_SIGMOID || out, GATMI_EINVAL, "ipd_bwd: the sigmoid needs the saved output");
+    IpdArgs a = {};
+    a.N = N; a.F = F; a.Z = Z; a.dOut = dOut; a.out_saved = activation == GATMI_ACT_SIGMOID ? out : nullptr;
+    a.dZ = dZ; a.keep = keep; a.seed = seed; a.activation = activation;
+    GATMI_IPD_LAUNCH(ipd_bwd_kernel, "ipd_bwd");
+    return GATMI_OK;
+}

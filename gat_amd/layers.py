@@ -252,3 +252,10 @@ class BNFAttention(nn.Module):
             outs.append(ops.bnf_aggregate(seq, net_mat, self.W[:, s].contiguous(), self.a1[s], self.a2[s], self.b1[s],
                                           self.b2[s], self.m1[s], self.m2[s]))
         return torch.cat(outs, dim=2)
+
+
+def InnerProductDecoder(seq, activation="sigmoid", dropout=0.0):
+    """utils/layers.py:307-313.  seq [B,N,F] -> flat [B*N*N] vector of activation(<z_i, z_j>) per
+    graph, as the reference returns it (callers reshape to [-1,N,N], models/gat.py:206).
+    activation: "sigmoid" (the reference's default, tf.nn.sigmoid) or "identity"."""
+    return ops.inner_product_decoder(seq, activation, dropout).reshape(-1)

@@ -363,3 +363,43 @@ class BnfAggregateFn(torch.autograd.Function):
 
 def bnf_aggregate(x, net_mat, W, a1, a2, b1, b2, m1, m2, slope=LEAKY_SLOPE):
     return BnfAggregateFn.apply(x, net_mat, W, a1, a2, b1, b2, m1, m2, float(slope))
+
+
+class InnerProductDecoderFn(torch.autograd.Function):
+    """utils/layers.py:307-313: act(dropout(z) . dropout(z)^T) per graph, z [B,N,F] -> [B,N,N]."""
+
+    @staticmethod
+    def forward(ctx, z, activation, keep, seed):
+        _require_cuda(z)
+        B, N, F = z.shape
+        zc = _f32(z).contiguous()
+        out = _new((B, N, N), zc)
+        _lib.call("gatmi_ipd_fwd", B, N, F, ptr(zc), activation, keep, seed, ptr(out), _lib.current_stream())
+        if ctx.needs_input_grad[0]:
+            ctx.args = (activation, keep, seed)
+            ctx.save_for_backward(zc, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        zc, out = ctx.saved_tensors
+        activation, keep, seed = ctx.args
+        B, N, F = zc.shape
+        dz = _new((B, N, F), zc)
+        _lib.call("gatmi_ipd_bwd", B, N, F, ptr(_f32(dout).contiguous()), ptr(out), ptr(zc), activation, keep, seed,
+                  ptr(dz), _lib.current_stream())
+        return dz, None, None, None
+
+
+def inner_product_decoder(z, activation="sigmoid", dropout=0.0, seed=None):
+    """sigmoid (or identity) of the Gram matrix of each graph's node embeddings; dropout is the
+    reference's rate on the inputs (layers.py:308), 0 = exact identity."""
+    act = {"sigmoid": _lib.ACT_SIGMOID, "identity": _lib.ACT_IDENTITY}.get(activation)
+    if act is None:
+        raise ValueError("activation must be 'sigmoid' or 'identity', got %r" % (activation,))
+    if z.shape[-1] > 128:
+        raise ValueError("inner_product_decoder: embedding width %d > 128" % z.shape[-1])
+    keep = 1.0 - float(dropout)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if keep < 1.0 else 0
+    return InnerProductDecoderFn.apply(z, act, keep, int(seed))

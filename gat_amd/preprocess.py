@@ -88,3 +88,33 @@ def load_random_data(size, rng=None):
     y_val[val_mask] = labels[val_mask]
     y_test[test_mask] = labels[test_mask]
     return adj, features, y_train, y_val, y_test, train_mask, val_mask, test_mask
+
+
+def pad_graphs(adjs, feats, labels=None):
+    """utils/process_ppi.py:183-215,255-269: stack graphs of different sizes into one padded batch.
+
+    Graph g keeps its adjacency in the leading sizes[g] x sizes[g] block; the padding is the
+    identity (process_ppi.py:194), padded feature and label rows are zero, and the node mask is 1
+    for real nodes.  Returns (adj [G,N,N] float64, feat [G,N,F] float64, sizes [G] int64,
+    node_mask [G,N] float64[, labels [G,N,C] float64]) with N = max size.  Feeding adj and sizes to
+    adj_to_bias gives the additive mask under which padded nodes attend to themselves only (their
+    diagonal entry is (I·(I+I)) = 2, hence a bias of +1e9, every other entry of their row -1e9)."""
+    sizes = np.array([a.shape[0] for a in adjs], dtype=np.int64)
+    n = int(sizes.max())
+    adj = np.empty((len(adjs), n, n))
+    feat = np.zeros((len(adjs), n, feats[0].shape[1]))
+    mask = np.zeros((len(adjs), n))
+    lab = None if labels is None else np.zeros((len(adjs), n, labels[0].shape[1]))
+    for g, a in enumerate(adjs):
+        s = int(sizes[g])
+        a = a.toarray() if sp.issparse(a) else np.asarray(a)
+        block = np.identity(n)
+        block[:s, :s] = a
+        adj[g] = block
+        f = feats[g]
+        feat[g, :s] = f.toarray() if sp.issparse(f) else np.asarray(f)
+        mask[g, :s] = 1.0
+        if lab is not None:
+            lab[g, :s] = labels[g]
+    out = (adj, feat, sizes, mask)
+    return out if lab is None else out + (lab,)

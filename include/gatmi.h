@@ -46,6 +46,7 @@ extern "C" {
 
 #define GATMI_ACT_IDENTITY 0    /* `lambda x: x`, models/sp_gat.py:30 */
 #define GATMI_ACT_ELU      1    /* tf.nn.elu,     models/sp_gat.py:9  */
+#define GATMI_ACT_SIGMOID  2    /* tf.nn.sigmoid, utils/layers.py:307 (inner-product decoder only) */
 
 #define GATMI_DTYPE_F32  0      /* storage of a gathered table: fp32 rows ...                      */
 #define GATMI_DTYPE_BF16 1      /* ... or bf16 rows (half the gather traffic; arithmetic stays fp32) */
@@ -241,6 +242,19 @@ int gatmi_bnf_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t fp,
                        const float *G, const float *stats, const float *X, const float *A,
                        const float *f2, const float *m1, const float *m2, float slope,
                        float *dX, float *dA, float *df2, float *dm, float *ws, void *stream);
+
+/* InnerProductDecoder (utils/layers.py:307-313): out[b,i,j] = act(<Zd[b,i,:], Zd[b,j,:]>) with
+ * Zd = dropout(Z, keep) (:308; the same counter-based mask as the feature dropout of the attention
+ * layers, keyed on seed and the element index; keep = 1 disables it) and act = GATMI_ACT_SIGMOID
+ * (the reference's default) or GATMI_ACT_IDENTITY.  Z [B,N,F], F <= 128; out [B,N,N] (the
+ * reference returns it flattened, :311: same memory). */
+int gatmi_ipd_fwd(int64_t B, int32_t N, int32_t F, const float *Z, int32_t activation,
+                  float keep, uint64_t seed, float *out, void *stream);
+
+/* Backward of the above: dZ [B,N,F] from dOut [B,N,N], the saved output (sigmoid only; may be NULL
+ * for the identity) and Z; same keep and seed as the forward call. */
+int gatmi_ipd_bwd(int64_t B, int32_t N, int32_t F, const float *dOut, const float *out,
+                  const float *Z, int32_t activation, float keep, uint64_t seed, float *dZ, void *stream);
 
 /* Halo exchange helpers (row-partitioned multi-GPU).  pack: dst[k, :] = src[idx[k], :] for
  * k < n_idx, rows of `width` floats (send buffer of Wh / f2 rows requested by a peer); rows are

@@ -122,3 +122,14 @@ def bnf_v2e_aggregate(x, net_mat, p):
     thr = (net_mat > 0).to(x.dtype)
     net1 = thr[:, None] * p["m2"][None, :, None, None] + net_mat[:, None]
     return torch.einsum("bhij,bjf->bihf", net1 * att, x)
+
+
+def inner_product_decoder(z, activation="sigmoid", keep=1.0, mask=None):
+    """InnerProductDecoder (utils/layers.py:307-313): inputs = dropout(seq, 1 - dropout) (:308),
+    x = inputs @ inputs^T per graph (:309-310), flattened (:311), activation (:312).
+    mask: the 0/1 keep mask of the dropout, same shape as z (tf.nn.dropout scales kept entries by
+    1/keep); None = no dropout.  Returns the flat [B*N*N] vector."""
+    inputs = z if mask is None else z * mask / keep
+    x = inputs @ inputs.transpose(1, 2)
+    x = x.reshape(-1)
+    return torch.sigmoid(x) if activation == "sigmoid" else x

@@ -93,3 +93,47 @@ def test_dense_equals_sparse_on_the_same_graph():
     b = ops.dense_gat_layer(xs[None], tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"],
                             torch.tensor(bm, device=dev), cfg)[0]
     assert_close(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-6, atol_scale=1e-6, what="dense vs sparse")
+
+
+def test_padded_batch_with_per_graph_sizes():
+    """Graphs of different sizes padded to one [G,N,N] batch (process_ppi.py:183-215) and masked by
+    adj_to_bias(adj, sizes): the binarised block covers each graph's own nodes, padded nodes keep
+    the raw (I+I) diagonal, i.e. a +1e9 bias, and therefore attend to themselves only.  Real
+    nodes' outputs equal those of the unpadded graph; everything is compared with the oracle."""
+    from gat_amd import ops, preprocess
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(17)
+    F, H, D = 10, 8, 8
+    ns = [37, 50, 12, 50, 1]
+    adjs, feats = [], []
+    for n in ns:
+        a = (rng.random((n, n)) < 0.15).astype(np.float64)
+        adjs.append(np.maximum(a, a.T))
+        feats.append(rng.normal(0, 1, (n, F)))
+    adj, x, sizes, node_mask = preprocess.pad_graphs(adjs, feats)
+    assert adj.shape == (5, 50, 50) and (node_mask.sum(1) == ns).all()
+    bm = preprocess.adj_to_bias(adj, sizes, nhood=1)
+    assert bm[2, 20, 20] == 1e9 and bm[2, 20, 21] == -1e9          # padded node: +1e9 on its diagonal
+    p = layer_params(F, H, D, seed=5)
+    tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+    xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
+    cfg = ops.make_cfg(H, D, activation="elu")
+    out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"],
+                              torch.tensor(bm, dtype=torch.float32, device=dev), cfg)
+    ref = ref_numpy.gat_layer_dense(x, p, bm, ref_numpy.elu, "concat")
+    assert_close(out.detach().cpu().numpy(), ref, what="padded forward")
+    # a real node's output does not depend on the padding
+    alone = ref_numpy.gat_layer_dense(feats[2][None], p, preprocess.adj_to_bias(adjs[2][None], [12]), ref_numpy.elu, "concat")
+    assert_close(out.detach().cpu().numpy()[2, :12], alone[0], what="padded vs unpadded")
+    # a padded node sees only itself: out = elu(Wh_i + bias) with Wh_i = 0 (zero features)
+    assert_close(out.detach().cpu().numpy()[2, 12:], np.broadcast_to(ref_numpy.elu(p["bias"].reshape(-1)), (38, H * D)),
+                 what="padded rows")
+    dout = rng.normal(0, 1, tuple(out.shape)) * node_mask[..., None]
+    out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
+    rp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    rout = ref_torch.layer_dense(rx, rp, torch.tensor(bm), "elu", "concat")
+    rout.backward(torch.tensor(dout))
+    assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what="padded dX")
+    for k in ("W", "a1", "a2", "bias"):
+        assert_close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), atol_scale=5e-6, what="padded d" + k)
