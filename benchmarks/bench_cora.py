@@ -30,25 +30,28 @@ def timed(fn, iters, sync):
 
 def main():
     from gat_amd import CSRGraph, layers, preprocess
+    from gat_amd.features import SparseFeatures
     from gat_amd.models import GAT, SpGAT
     dev = torch.device("cuda:0")
     n, f, c = 2708, 1433, 7
     rng = np.random.RandomState(0)
     adj = sp.random(n, n, density=0.001, random_state=rng, format="csr")
     adj = ((adj + adj.T) > 0).astype(np.float64)
-    feats = preprocess.preprocess_features(sp.random(n, f, density=0.0127, random_state=rng, format="csr"))[0]
+    feats, feats_tuple = preprocess.preprocess_features(sp.random(n, f, density=0.0127, random_state=rng, format="csr"))
     triple = preprocess.preprocess_adj_bias(adj)
     graph = CSRGraph.from_reference_triple(triple, dev)
     bias = torch.tensor(preprocess.adj_to_bias(np.asarray(adj.todense())[None], [n], 1), dtype=torch.float32, device=dev)
     x = torch.tensor(np.asarray(feats)[None], dtype=torch.float32, device=dev)
+    xs = SparseFeatures.from_tuple(feats_tuple, dev)          # the same features, stored entries only
     kw = dict(hid_units=[8], n_heads=[8, 1], activation=layers.elu, residual=False)
     res = {"nodes": n, "entries": graph.nnz}
-    for name, model, g in (("sparse", SpGAT, graph), ("dense", GAT, bias)):
+    res["feature_entries"] = xs.nnz
+    for name, model, g, inp in (("sparse", SpGAT, graph, x), ("sparse_spfeat", SpGAT, graph, xs), ("dense", GAT, bias, x)):
         store = layers.VariableStore()
 
         def step():
             with layers.variable_scope(store):
-                out = model.inference(x, c, n, False, 0.0, 0.0, bias_mat=g, **kw)
+                out = model.inference(inp, c, n, False, 0.0, 0.0, bias_mat=g, **kw)
             for p in store.parameters():
                 p.grad = None
             out.sum().backward()

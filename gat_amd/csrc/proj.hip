@@ -307,6 +307,51 @@ __global__ __launch_bounds__(256) void logit_halves_kernel(const float *Wh, int6
 }
 
 // ------------------------------------------------------------------------------------------
+// out[r, :] = sum_k val[k] * M[idx[k], :] over the stored entries k of row r of a CSR matrix:
+// the projection Wh = X . W for sparse node features (X in CSR, M = W) and, with the CSR of X^T
+// and M = dWh, the weight gradient dW = X^T . dWh.  G = width/4 lanes per row, entries in stored
+// order (fixed summation order).  With a1 != nullptr the logit halves f1 / f2 of the finished row
+// are written as well.
+// ------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void spmm_rows_kernel(const int64_t *rowptr, const int32_t *idx, const float *val,
+                                                         int64_t n_rows, const float *M, float *out, int H, int LPH,
+                                                         const float *a1, const float *a2, const float *b1,
+                                                         const float *b2, float *f1, float *f2) {
+    constexpr int RPW = 64 / G;
+    constexpr int HD = 4 * G;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, grp = lane / G;
+    const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+    for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp; row < n_rows; row += stride) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int64_t end = rowptr[row + 1];
+        for (int64_t k = rowptr[row]; k < end; ++k) {
+            const float v = val[k];
+            const float4 m = *reinterpret_cast<const float4 *>(M + (int64_t)idx[k] * HD + sub * 4);
+            acc.x = fmaf(v, m.x, acc.x); acc.y = fmaf(v, m.y, acc.y);
+            acc.z = fmaf(v, m.z, acc.z); acc.w = fmaf(v, m.w, acc.w);
+        }
+        *reinterpret_cast<float4 *>(out + row * HD + sub * 4) = acc;
+        if (a1) {
+            const float4 a1v = *reinterpret_cast<const float4 *>(a1 + sub * 4);
+            const float4 a2v = *reinterpret_cast<const float4 *>(a2 + sub * 4);
+            float p1 = acc.x * a1v.x + acc.y * a1v.y + acc.z * a1v.z + acc.w * a1v.w;
+            float p2 = acc.x * a2v.x + acc.y * a2v.y + acc.z * a2v.z + acc.w * a2v.w;
+            for (int o = 1; o < LPH; o <<= 1) {
+                p1 += __shfl_xor(p1, o, 64);
+                p2 += __shfl_xor(p2, o, 64);
+            }
+            if (sub % LPH == 0) {
+                const int head = sub / LPH;
+                f1[row * H + head] = p1 + b1[head];
+                f2[row * H + head] = p2 + b2[head];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // dW = X^T . dWh, reduced over nodes.  Block (bx, by): node chunks bx, bx+gridDim.x, ...;
 // feature rows [by*16*MT, +16*MT).  Each wave keeps an [16*MT x 16*NT] partial in registers.
 // ------------------------------------------------------------------------------------------
@@ -614,9 +659,79 @@ static int launch_xt_gemm(const float *X, int64_t n, int F, int64_t ldx, const f
     return GATMI_OK;
 }
 
+// preprocess_features (utils/process.py:155-162) for a CSR matrix: out = val / rowsum, rows that
+// sum to zero stay zero (r_inv = inf is replaced by 0 there).  One thread per row, stored order.
+__global__ void csr_row_normalize_kernel(int64_t n, const int64_t *rowptr, const float *val, float *out) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const int64_t b = rowptr[row], e = rowptr[row + 1];
+    float sum = 0.f;
+    for (int64_t k = b; k < e; ++k) sum += val[k];
+    float r_inv = 1.0f / sum;
+    if (isinf(r_inv)) r_inv = 0.f;
+    for (int64_t k = b; k < e; ++k) out[k] = val[k] * r_inv;
+}
+
+template <int G>
+static int launch_spmm_rows(const int64_t *rowptr, const int32_t *idx, const float *val, int64_t n_rows, const float *M,
+                            float *out, int H, int LPH, const float *a1, const float *a2, const float *b1,
+                            const float *b2, float *f1, float *f2, hipStream_t st, const char *name) {
+    const int64_t rows_per_block = 4 * (64 / G);
+    const int64_t nb = std::min<int64_t>((n_rows + rows_per_block - 1) / rows_per_block, 1 << 20);
+    hipLaunchKernelGGL(spmm_rows_kernel<G>, dim3((unsigned)nb), dim3(256), 0, st, rowptr, idx, val, n_rows, M, out, H, LPH,
+                       a1, a2, b1, b2, f1, f2);
+    GATMI_LAUNCH_CHECK(name);
+    return GATMI_OK;
+}
+
 }  // namespace gatmi
 
 using namespace gatmi;
+
+extern "C" int gatmi_proj_fwd_csr(const int64_t *xrowptr, const int32_t *xcol, const float *xval, int64_t n, int32_t f_in,
+                                  const float *W, const float *a1, const float *a2, const float *b1, const float *b2,
+                                  int32_t H, int32_t dp, float *Wh, float *f1, float *f2, void *stream) {
+    int G, LPH;
+    int rc = check_shape(H, dp, &G, &LPH);
+    if (rc) return rc;
+    GATMI_REQUIRE(n >= 0 && f_in > 0, GATMI_EINVAL, "proj_fwd_csr: bad dims n=%lld f_in=%d", (long long)n, f_in);
+    if (n == 0) return GATMI_OK;
+    GATMI_REQUIRE(xrowptr && xcol && xval && W && Wh, GATMI_EINVAL, "proj_fwd_csr: null pointer");
+    const bool logits = f1 || f2;
+    GATMI_REQUIRE(!logits || (f1 && f2 && a1 && a2 && b1 && b2), GATMI_EINVAL, "proj_fwd_csr: f1, f2, a1, a2, b1, b2 go together");
+    GATMI_REQUIRE_ALIGNED(W); GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(a1); GATMI_REQUIRE_ALIGNED(a2);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!logits) a1 = a2 = nullptr;
+#define X_(gg) if (G == gg) return launch_spmm_rows<gg>(xrowptr, xcol, xval, n, W, Wh, H, LPH, a1, a2, b1, b2, f1, f2, st, "proj_fwd_csr");
+    X_(1) X_(2) X_(4) X_(8) X_(16) X_(32) X_(64)
+#undef X_
+    return fail(GATMI_EUNSUPPORTED, "proj_fwd_csr: no kernel for %d lanes per row", G);
+}
+
+extern "C" int gatmi_proj_bwd_params_csr(const int64_t *xt_rowptr, const int32_t *xt_row, const float *xt_val,
+                                         int64_t n, int32_t f_in, const float *dWh, const float *Wh,
+                                         const float *df1, const float *df2, int32_t H, int32_t dp,
+                                         float *dW, float *da1, float *da2, float *db1, float *db2,
+                                         float *ws, void *stream) {
+    int G, LPH;
+    int rc = check_shape(H, dp, &G, &LPH);
+    if (rc) return rc;
+    GATMI_REQUIRE(n >= 0 && f_in > 0, GATMI_EINVAL, "proj_bwd_params_csr: bad dims");
+    GATMI_REQUIRE(xt_rowptr && dWh && dW, GATMI_EINVAL, "proj_bwd_params_csr: null pointer");
+    GATMI_REQUIRE(!Wh || (df1 && df2 && da1 && da2 && db1 && db2 && ws), GATMI_EINVAL, "proj_bwd_params_csr: Wh needs df1, df2, da1, da2, db1, db2, ws");
+    GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(ws); GATMI_REQUIRE_ALIGNED(dWh); GATMI_REQUIRE_ALIGNED(dW);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (Wh) {
+#define X_(gg) if (G == gg) rc = launch_attn_param_grad<gg>(Wh, df1, df2, n, H, LPH, ws, da1, da2, db1, db2, st);
+        X_(1) X_(2) X_(4) X_(8) X_(16) X_(32) X_(64)
+#undef X_
+        if (rc) return rc;
+    }
+#define X_(gg) if (G == gg) return launch_spmm_rows<gg>(xt_rowptr, xt_row, xt_val, f_in, dWh, dW, H, LPH, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st, "proj_bwd_params_csr");
+    X_(1) X_(2) X_(4) X_(8) X_(16) X_(32) X_(64)
+#undef X_
+    return fail(GATMI_EUNSUPPORTED, "proj_bwd_params_csr: no kernel for %d lanes per row", G);
+}
 
 extern "C" int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t ldx,
                               const float *W, const float *a1, const float *a2,
@@ -725,4 +840,14 @@ extern "C" int gatmi_proj_bwd_input(const float *dWh, int64_t n, int32_t f_in, c
     g.B = W; g.sbk = 1; g.sbc = hd; g.Nc = f_in;   // B[k=c_hd][c=f] = W[f][c_hd]
     g.C = dX; g.ldc = lddx; g.accumulate = accumulate; g.cbias = nullptr;
     return launch_tall_gemm(g, reinterpret_cast<hipStream_t>(stream), "proj_bwd_input");
+}
+
+extern "C" int gatmi_csr_row_normalize(int64_t n, const int64_t *rowptr, const float *val, float *out, void *stream) {
+    GATMI_REQUIRE(n >= 0, GATMI_EINVAL, "csr_row_normalize: negative size");
+    if (n == 0) return GATMI_OK;
+    GATMI_REQUIRE(rowptr && val && out, GATMI_EINVAL, "csr_row_normalize: null pointer");
+    hipLaunchKernelGGL(csr_row_normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), n, rowptr, val, out);
+    GATMI_LAUNCH_CHECK("csr_row_normalize");
+    return GATMI_OK;
 }

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .features import SparseFeatures
 from .graph import CSRGraph
 
 elu = "elu"
@@ -83,6 +84,17 @@ class GATHeads(nn.Module):
         act = _activation_name(activation)
         if isinstance(graph_or_bias, CSRGraph) and seq.dim() == 3:           # batch is 1 on the sparse path
             return self.forward(seq[0], graph_or_bias, act, reduce, in_drop, coef_drop, training, seed)[None]
+        if isinstance(seq, SparseFeatures):                                  # sparse node features stand for [1,N,F]
+            if not isinstance(graph_or_bias, CSRGraph):
+                raise ValueError("sparse node features go with the sparse attention head (sp_attn_head)")
+            if training and in_drop > 0.0:
+                seq = seq.dropout(in_drop)
+            groups = _head_groups(H, D)
+            if len(groups) != 1:
+                raise ValueError("sparse node features: %d heads of width %d need more than one sweep" % (H, D))
+            if seed is None and training and (in_drop > 0.0 or coef_drop > 0.0):
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            return self._run(seq, graph_or_bias, slice(0, H), act, reduce, in_drop, coef_drop, training, seed)[None]
         if training and in_drop > 0.0:
             seq = torch.nn.functional.dropout(seq, in_drop, True)            # layers.py:8-9
         if seed is None and training and (in_drop > 0.0 or coef_drop > 0.0):

@@ -9,6 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import ptr
+from .features import SparseFeatures
 
 LEAKY_SLOPE = 0.2  # tf.nn.leaky_relu default, utils/layers.py:17
 
@@ -57,8 +58,13 @@ def _new(shape, like, dtype=torch.float32):
 
 
 def _project(x2d, W, a1, a2, b1, b2, cfg, W_res=None, b_res=None):
-    """K1: Wh = X.W (+ f1, f2) on [n, F] rows.  Returns padded parameter views and outputs."""
+    """K1: Wh = X.W (+ f1, f2) on [n, F] rows (dense tensor or SparseFeatures).  Returns padded
+    parameter views and outputs."""
     n, F = x2d.shape
+    sparse_x = isinstance(x2d, SparseFeatures)
+    if sparse_x and W_res is not None:
+        raise ValueError("sparse node features: the residual projection is not built (the reference's first "
+                         "layer has residual=False, models/sp_gat.py:16)")
     H, D, dp = cfg.H, cfg.D, cfg.dp
     hd = H * dp
     Wp = _pad_last(W.reshape(F, H, D), D, dp).reshape(F, hd)
@@ -73,6 +79,10 @@ def _project(x2d, W, a1, a2, b1, b2, cfg, W_res=None, b_res=None):
         Wrp = _pad_last(W_res.reshape(F, H, D), D, dp).reshape(F, hd)
         brp = _pad_last(b_res.reshape(H, D), D, dp).reshape(hd)
         res = _new((n, hd), x2d)
+    if sparse_x:
+        _lib.call("gatmi_proj_fwd_csr", ptr(x2d.rowptr), ptr(x2d.col), ptr(x2d.val), n, F, ptr(Wp), ptr(a1p), ptr(a2p),
+                  ptr(b1c), ptr(b2c), H, dp, ptr(Wh), ptr(f1), ptr(f2), _lib.current_stream())
+        return Wp, a1p, a2p, None, Wh, f1, f2, None
     _lib.call("gatmi_proj_fwd", ptr(x2d), n, F, x2d.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1c), ptr(b2c),
               H, dp, ptr(Wh), ptr(f1), ptr(f2), ptr(Wrp), ptr(brp), ptr(res), _lib.current_stream())
     return Wp, a1p, a2p, Wrp, Wh, f1, f2, res
@@ -88,6 +98,13 @@ def _project_backward(x2d, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, need_dx):
     dW = _new((F, hd), x2d)
     da1, da2 = _new((hd,), x2d), _new((hd,), x2d)
     db1, db2 = _new((H,), x2d), _new((H,), x2d)
+
+    def unpad(t, lead):
+        return t.reshape(*lead, H, dp)[..., :D]
+    if isinstance(x2d, SparseFeatures):
+        _lib.call("gatmi_proj_bwd_params_csr", ptr(x2d.t_rowptr), ptr(x2d.t_row), ptr(x2d.t_val), n, F, ptr(dWh), ptr(Wh),
+                  ptr(df1), ptr(df2), H, dp, ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(ws), st)
+        return None, unpad(dW, (F,)), unpad(da1, ()), unpad(da2, ()), db1, db2, None
     _lib.call("gatmi_proj_bwd_params", ptr(x2d), n, F, x2d.stride(0), ptr(dWh), ptr(Wh), ptr(df1), ptr(df2), H, dp,
               ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(ws), st)
     dWr = None
@@ -101,9 +118,6 @@ def _project_backward(x2d, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, need_dx):
         _lib.call("gatmi_proj_bwd_input", ptr(dWh), n, F, ptr(Wp), H, dp, ptr(dx), F, 0, st)
         if Wrp is not None:
             _lib.call("gatmi_proj_bwd_input", ptr(g), n, F, ptr(Wrp), H, dp, ptr(dx), F, 1, st)
-
-    def unpad(t, lead):
-        return t.reshape(*lead, H, dp)[..., :D]
     return (dx, unpad(dW, (F,)), unpad(da1, ()), unpad(da2, ()), db1, db2,
             None if dWr is None else unpad(dWr, (F,)))
 
@@ -114,7 +128,9 @@ class SparseGATLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, a1, a2, b1, b2, bias, W_res, b_res, graph, cfg):
         _require_cuda(x, W)
-        x = _f32(x).contiguous()
+        sparse_x = isinstance(x, SparseFeatures)
+        if not sparse_x:
+            x = _f32(x).contiguous()
         n, F = x.shape
         if n != graph.n_dst or graph.n_src != graph.n_dst:
             raise ValueError("x has %d rows but the graph is %d x %d" % (n, graph.n_dst, graph.n_src))
@@ -145,7 +161,8 @@ class SparseGATLayerFn(torch.autograd.Function):
         if need_grad:
             ctx.graph, ctx.cfg = graph, cfg
             ctx.has_bias, ctx.has_res = bias is not None, W_res is not None
-            ctx.save_for_backward(x, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q)
+            ctx.sparse_x = x if sparse_x else None
+            ctx.save_for_backward(x.val if sparse_x else x, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q)
         if cfg.reduce == "mean":
             return out[:, :D] if D != dp else out
         return out.reshape(n, H, dp)[:, :, :D].reshape(n, H * D) if D != dp else out
@@ -156,6 +173,8 @@ class SparseGATLayerFn(torch.autograd.Function):
         graph, cfg = ctx.graph, ctx.cfg
         H, D, dp = cfg.H, cfg.D, cfg.dp
         hd = H * dp
+        if ctx.sparse_x is not None:
+            x = ctx.sparse_x
         n = x.shape[0]
         st = _lib.current_stream()
         if cfg.reduce == "mean":

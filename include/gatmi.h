@@ -135,6 +135,28 @@ int gatmi_proj_bwd_input(const float *dWh, int64_t n, int32_t f_in, const float 
                          int32_t H, int32_t dp, float *dX, int64_t lddx, int accumulate,
                          void *stream);
 
+/* The projection for SPARSE node features: X [n, f_in] in CSR (xrowptr [n+1], xcol, xval in DEVICE
+ * memory), as the sparse tuple of preprocess_features (utils/process.py:155-162, the second return
+ * value) describes it; Cora's features are 98.7 % zeros.  Wh = X . W summed over stored entries
+ * in stored order, logit halves as in gatmi_proj_fwd.  No residual projection. */
+int gatmi_proj_fwd_csr(const int64_t *xrowptr, const int32_t *xcol, const float *xval, int64_t n, int32_t f_in,
+                       const float *W, const float *a1, const float *a2, const float *b1, const float *b2,
+                       int32_t H, int32_t dp, float *Wh, float *f1, float *f2, void *stream);
+
+/* preprocess_features (utils/process.py:155-162) on a device CSR matrix: out[k] = val[k] * (1 / sum
+ * of the row's stored values), rows whose sum is 0 stay 0 (the reference replaces the infinite
+ * reciprocal by 0, :159).  val and out may be the same array. */
+int gatmi_csr_row_normalize(int64_t n, const int64_t *rowptr, const float *val, float *out, void *stream);
+
+/* Parameter gradients for sparse features: dW = X^T . dWh walks the CSR of X^T (xt_rowptr [f_in+1],
+ * xt_row = node ids, xt_val; fixed summation order); da1, da2, db1, db2 as in gatmi_proj_bwd_params
+ * (ws: gatmi_proj_bwd_ws_floats floats, needed only when Wh is given). */
+int gatmi_proj_bwd_params_csr(const int64_t *xt_rowptr, const int32_t *xt_row, const float *xt_val,
+                              int64_t n, int32_t f_in, const float *dWh, const float *Wh,
+                              const float *df1, const float *df2, int32_t H, int32_t dp,
+                              float *dW, float *da1, float *da2, float *db1, float *db2,
+                              float *ws, void *stream);
+
 /* Fused CSR edge-softmax + neighbour aggregation, forward.  Replaces utils/layers.py:16-17
  * (logits, LeakyReLU, additive mask, softmax), :20 (coefficient dropout), :22 (feature dropout),
  * :24 (coefs . seq_fts), :25 (bias_add), :30 (residual add), :34 (activation) and the head

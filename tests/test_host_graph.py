@@ -144,3 +144,25 @@ def test_partition_and_halo_plan():
         assert (table[cl] == cg).all()
         seen[lo:hi] = True
     assert seen.all()
+
+
+def test_sparse_features_index_preparation():
+    """CSR and transposed CSR of a feature matrix built from the reference's sparse tuple
+    (utils/process.py:125-141): same entries as scipy's, transposed entries in node order."""
+    import scipy.sparse as sp
+    import torch
+    from gat_amd import preprocess
+    from gat_amd.features import SparseFeatures
+    rng = np.random.RandomState(3)
+    x = sp.random(60, 35, density=0.1, random_state=rng, format="coo", dtype=np.float32)
+    f = SparseFeatures.from_tuple(preprocess.sparse_to_tuple(x), "cpu")
+    csr = x.tocsr()
+    csr.sort_indices()
+    assert (f.rowptr.numpy() == csr.indptr).all() and (f.col.numpy() == csr.indices).all()
+    assert (f.val.numpy() == csr.data).all()
+    t = x.T.tocsr()
+    t.sort_indices()
+    assert (f.t_rowptr.numpy() == t.indptr).all() and (f.t_row.numpy() == t.indices).all()
+    assert (f.t_val.numpy() == t.data).all()
+    assert f.t_rowptr.dtype == torch.int64 and f.t_row.dtype == torch.int32
+    assert (f.to_dense().numpy() == x.toarray()).all()
