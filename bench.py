@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--workload", choices=["products", "cora"], default="products",
                     help="products: the headline (default); cora: the two-layer Cora network, GPU vs the CPU restatement")
+    ap.add_argument("--halo", choices=["replicate", "exchange"], default="replicate",
+                    help="N > 1 only.  replicate (default): the layer is a first layer, its constant input rows of the halo "
+                         "sources are fetched once at set-up and projected locally, so a step communicates only the all-reduce "
+                         "of the parameter gradients; exchange: Wh / f2 rows and their gradients travel every step (RCCL all-to-all)")
     ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
                     help="bf16: gathered tables in bf16 (2e-2 parity class); the headline is f32")
     return ap.parse_args()
@@ -219,7 +223,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-        layer_step, E_rank, info = gdist.build_bench_step(rank, world, n_own, e_own, F_IN, HEADS, WIDTH, dev, chunk, args.storage)
+        layer_step, E_rank, info = gdist.build_bench_step(rank, world, n_own, e_own, F_IN, HEADS, WIDTH, dev, chunk, args.storage, args.halo)
     else:
         dst, src = synth.rmat_graph(n_own, e_own, 4, dev)
         graph = CSRGraph.from_device_coo(dst, src, n_own, n_own, chunk=chunk)
@@ -296,7 +300,11 @@ def main():
             "config": {"workload": "R-MAT power-law graph at ogbn-products shape per GPU: %d nodes, %d edge entries "
                                    "(self-loops included), %d-d features, %d heads x %d, ELU, fwd+bwd of one layer"
                                    % (n_own, E_rank, F_IN, HEADS, WIDTH),
-                       "partitioning": "single GPU" if world == 1 else "row-partitioned x%d, RCCL halo all-to-all" % world},
+                       "partitioning": "single GPU" if world == 1 else (
+                           "row-partitioned x%d, " % world + (
+                               "halo sources' input rows replicated at set-up and projected locally; per step one RCCL "
+                               "all-reduce of the parameter gradients" if args.halo == "replicate" else
+                               "RCCL all-to-all of halo Wh/f2 rows (forward) and of their gradients (backward) every step"))},
             "roofline": roofline,
             "layer_roofline": {"bound": "hbm", "alg_bytes": lb, "achieved": round(lg, 1), "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": round(lg / HBM_PEAK_GBPS, 4)},

@@ -12,6 +12,15 @@ listed once per (owner, requester) pair, sorted by global id, and appended after
             reverse all-to-all(v) of the halo rows' dWh / df2 contributions -> add at the owner ->
             finish owned rows -> parameter gradients on owned rows (+ one small all-reduce)
 
+For a FIRST layer the exchange can be traded for memory: its input X is constant over training and
+needs no gradient, so every rank fetches the X rows of its halo sources once (`replicate_rows`) and
+from then on projects owned + halo rows itself (halo="replicate").  The forward pass then needs no
+communication at all, and the backward pass none either: each rank adds its share of dW = X^T.dWh
+and of da2 / db2 over owned + halo rows and the small all-reduce of the parameter gradients
+completes the sums.  The price is the projection and the weight gradient over n_own + n_halo rows
+instead of n_own, and (n_halo x F) floats of the 288 GB of HBM.  Deeper layers (input produced by
+the previous layer, gradient needed) use the exchange.
+
 Each peer pair exchanges directly (xGMI is point to point: an all-to-all keeps all 7 links busy,
 a ring would be bound by one).  With the "gloo" backend (CPU rehearsal, or several ranks sharing
 one GPU in tests) buffers are staged through host memory.
@@ -169,6 +178,15 @@ class PartitionedGraph:
         ex = HaloExchange(rank, world, n_own, halo, counts, lo, dst_global.device, group)
         return cls(g, ex, part, rank)
 
+    def replicate_rows(self, x_own):
+        """x_own [n_own, F] -> [n_own + n_halo, F]: the owned rows followed by the halo sources' rows
+        fetched from their owners (one exchange, at set-up).  Input of the layer with halo="replicate"."""
+        x_own = ops._f32(x_own).contiguous()
+        full = torch.empty((self.n_own + self.n_halo, x_own.shape[1]), dtype=torch.float32, device=x_own.device)
+        full[:self.n_own] = x_own
+        self.exchange.gather_halo(full, x_own.shape[1])
+        return full
+
 
 # ------------------------------------------------------------------------------------------------
 # the layer
@@ -177,28 +195,40 @@ class DistSparseGATLayerFn(torch.autograd.Function):
     """SparseGATLayerFn with the halo exchange between the projection and the aggregation."""
 
     @staticmethod
-    def forward(ctx, x, W, a1, a2, b1, b2, bias, pgraph, cfg):
+    def forward(ctx, x, W, a1, a2, b1, b2, bias, pgraph, cfg, replicate=False):
         ops._require_cuda(x, W)
         x = ops._f32(x).contiguous()
         graph, ex = pgraph.graph, pgraph.exchange
-        n, F = x.shape
-        if n != graph.n_dst:
-            raise ValueError("x has %d rows but this rank owns %d" % (n, graph.n_dst))
+        F = x.shape[1]
+        n, n_src = graph.n_dst, graph.n_src
+        if replicate:
+            if x.shape[0] != n_src:
+                raise ValueError("halo='replicate': x must hold owned + halo rows (%d, from replicate_rows), got %d"
+                                 % (n_src, x.shape[0]))
+            if ctx.needs_input_grad[0]:
+                raise ValueError("halo='replicate' is for constant inputs (a first layer): the gradient of replicated "
+                                 "rows would have to travel back to their owners; use the exchange")
+        elif x.shape[0] != n:
+            raise ValueError("x has %d rows but this rank owns %d" % (x.shape[0], n))
         H, D, dp = cfg.H, cfg.D, cfg.dp
         hd = H * dp
-        n_src = graph.n_src
         st = _lib.current_stream()
         Wp = ops._pad_last(W.reshape(F, H, D), D, dp).reshape(F, hd)
         a1p = ops._pad_last(a1.reshape(H, D), D, dp).reshape(hd)
         a2p = ops._pad_last(a2.reshape(H, D), D, dp).reshape(hd)
+        n_proj = n_src if replicate else n          # rows this rank projects itself
         feat = ops._new((n_src, hd), x)
         f2 = ops._new((n_src, H), x)
-        f1 = ops._new((n, H), x)
-        _lib.call("gatmi_proj_fwd", ptr(x), n, F, x.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1.contiguous()),
+        f1 = ops._new((n_proj, H), x)
+        _lib.call("gatmi_proj_fwd", ptr(x), n_proj, F, x.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1.contiguous()),
                   ptr(b2.contiguous()), H, dp, ptr(feat), ptr(f1), ptr(f2), None, None, None, st)
         bf16 = cfg.storage == "bf16"
         gtab, gdt = feat, _lib.DTYPE_F32
-        if bf16:
+        if replicate:
+            if bf16:
+                gtab, gdt = torch.empty((n_src, hd), dtype=torch.bfloat16, device=x.device), _lib.DTYPE_BF16
+                _lib.call("gatmi_to_bf16", ptr(feat), n_src * hd, ptr(gtab), st)
+        elif bf16:
             # bf16 mode: the gathered table and therefore the halo rows on the wire are bf16 (half the
             # forward exchange); the owned fp32 rows stay for the parameter gradients
             gtab, gdt = torch.empty((n_src, hd), dtype=torch.bfloat16, device=x.device), _lib.DTYPE_BF16
@@ -207,7 +237,8 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             feat[n:].copy_(gtab[n:])        # the per-source backward sweep reads its own Wh row in fp32 (exact widening)
         else:
             ex.gather_halo(feat, hd)
-        ex.gather_halo(f2, H)
+        if not replicate:
+            ex.gather_halo(f2, H)
         biasp = None if bias is None else ops._pad_last(bias.reshape(H, D), D, dp).reshape(hd)
         need_grad = any(ctx.needs_input_grad)
         out = ops._new((n, dp if cfg.reduce == "mean" else hd), x)
@@ -224,7 +255,7 @@ class DistSparseGATLayerFn(torch.autograd.Function):
                   ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
                   ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
         if need_grad:
-            ctx.pgraph, ctx.cfg, ctx.has_bias = pgraph, cfg, bias is not None
+            ctx.pgraph, ctx.cfg, ctx.has_bias, ctx.replicate = pgraph, cfg, bias is not None, replicate
             ctx.save_for_backward(x, Wp, a1p, a2p, feat, f1, f2, out, agg, pos, lse, q)
         if cfg.reduce == "mean":
             return out[:, :D] if D != dp else out
@@ -237,7 +268,8 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         graph, ex = pgraph.graph, pgraph.exchange
         H, D, dp = cfg.H, cfg.D, cfg.dp
         hd = H * dp
-        n, n_src = x.shape[0], graph.n_src
+        n, n_src = graph.n_dst, graph.n_src
+        replicate = ctx.replicate
         st = _lib.current_stream()
         if cfg.reduce == "mean":
             dout = ops._pad_last(dout, D, dp)
@@ -247,7 +279,11 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         g = None if bf16 else ops._new((n, hd), x)
         g16 = torch.empty((n, hd), dtype=torch.bfloat16, device=x.device) if bf16 else None
         stats = ops._new((n, 3 * H), x)
-        df1 = ops._new((n, H), x)
+        if replicate:
+            # halo rows are no destinations here: their logit gradient df1 belongs to their owner
+            df1 = torch.zeros((n_src, H), dtype=torch.float32, device=x.device)
+        else:
+            df1 = ops._new((n, H), x)
         dbias = ops._new((hd,), x)
         ws = ops._new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x)
         _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out), ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse),
@@ -262,17 +298,29 @@ class DistSparseGATLayerFn(torch.autograd.Function):
                   ptr(graph.rowidx), ptr(graph.perm), ptr(g16 if bf16 else g), _lib.DTYPE_BF16 if bf16 else _lib.DTYPE_F32,
                   ptr(stats), ptr(feat), ptr(f2), None, None, None,
                   cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dfeat), ptr(df2), ptr(ws2), st)
+        if replicate:
+            # this rank's share of every sum over sources, on owned + halo rows; the all-reduce of the
+            # parameter gradients adds the shares of the other ranks
+            _lib.call("gatmi_gat_bwd_finalize", n_src, H, dp, ptr(df1), ptr(df2), ptr(a1p), ptr(a2p), ptr(dfeat), st)
+            _, dW, da1, da2, db1, db2, _ = ops._project_backward(x, Wp, None, feat, dfeat, df1, df2, g, cfg, False)
+            db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None
+            return None, dW, da1, da2, db1, db2, db, None, None, None
         ex.scatter_add_halo(dfeat, hd)
         ex.scatter_add_halo(df2, H)
         _lib.call("gatmi_gat_bwd_finalize", n, H, dp, ptr(df1), ptr(df2), ptr(a1p), ptr(a2p), ptr(dfeat), st)
         dWh = dfeat[:n]
         dx, dW, da1, da2, db1, db2, _ = ops._project_backward(x, Wp, None, feat, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
         db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None
-        return dx, dW, da1, da2, db1, db2, db, None, None
+        return dx, dW, da1, da2, db1, db2, db, None, None, None
 
 
-def dist_sparse_gat_layer(x, W, a1, a2, b1, b2, bias, pgraph, cfg):
-    return DistSparseGATLayerFn.apply(x, W, a1, a2, b1, b2, bias, pgraph, cfg)
+def dist_sparse_gat_layer(x, W, a1, a2, b1, b2, bias, pgraph, cfg, halo="exchange"):
+    """halo="exchange": x [n_own, F], Wh / f2 rows of halo sources travel every step (any layer).
+    halo="replicate": x [n_own + n_halo, F] from pgraph.replicate_rows (constant first-layer input):
+    no communication besides the all-reduce of the parameter gradients."""
+    if halo not in ("exchange", "replicate"):
+        raise ValueError("halo must be 'exchange' or 'replicate'")
+    return DistSparseGATLayerFn.apply(x, W, a1, a2, b1, b2, bias, pgraph, cfg, halo == "replicate")
 
 
 def allreduce_grads(params, group=None):
@@ -293,7 +341,8 @@ def allreduce_grads(params, group=None):
         off += g.numel()
 
 
-def build_bench_step(rank, world, n_own, e_own, f_in, heads, width, device, chunk=DEFAULT_CHUNK, storage="f32"):
+def build_bench_step(rank, world, n_own, e_own, f_in, heads, width, device, chunk=DEFAULT_CHUNK, storage="f32",
+                     halo="replicate"):
     """bench.py's N > 1 workload: every rank owns n_own destination rows of an R-MAT graph with
     world * n_own nodes and generates its own e_own in-edges (sources over the whole id range)."""
     from . import synth
@@ -304,6 +353,8 @@ def build_bench_step(rank, world, n_own, e_own, f_in, heads, width, device, chun
     pg = PartitionedGraph.from_device_edges(dst, src, part, rank, world, chunk)
     del dst, src
     x = synth.normal((n_own, f_in), 5 + 1000 * rank, device)
+    if halo == "replicate":
+        x = pg.replicate_rows(x)            # set-up, outside the timed step: the input features are constant
     dout = synth.normal((n_own, heads * width), 8 + 1000 * rank, device)
     m = GATHeads(f_in, heads, width, device=device)
     m.load(synth.glorot_layer(f_in, heads, width, 7, device))
@@ -314,9 +365,9 @@ def build_bench_step(rank, world, n_own, e_own, f_in, heads, width, device, chun
     def step():
         for p in params:
             p.grad = None
-        out = dist_sparse_gat_layer(x, m.W, m.a1, m.a2, m.b1, m.b2, m.bias, pg, cfg)
+        out = dist_sparse_gat_layer(x, m.W, m.a1, m.a2, m.b1, m.b2, m.bias, pg, cfg, halo)
         out.backward(dout)
         allreduce_grads(params)
 
-    info = {"graph": repr(pg.graph), "n_halo": pg.n_halo, "n_send": pg.exchange.n_send}
+    info = {"graph": repr(pg.graph), "n_halo": pg.n_halo, "n_send": pg.exchange.n_send, "halo": halo}
     return step, pg.graph.nnz, info

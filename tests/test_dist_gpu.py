@@ -52,6 +52,27 @@ def _worker(rank, world, port, q):
         assert_close(xd.grad.cpu().numpy(), xs.grad.cpu().numpy()[lo:hi], rtol=1e-5, atol_scale=2e-6, what="dX")
         for k in p:
             assert_close(dp_[k].grad.cpu().numpy(), tp[k].grad.cpu().numpy(), rtol=1e-5, atol_scale=5e-6, what="d" + k)
+        # first-layer mode: halo sources' input rows replicated once, no exchange inside the step
+        r_ = leaves()
+        xr = pg.replicate_rows(torch.tensor(x[lo:hi], device=dev))
+        assert xr.shape[0] == pg.n_own + pg.n_halo
+        halo_ids = np.setdiff1d(np.unique(col[int(rowptr[lo]):int(rowptr[hi])]), np.arange(lo, hi))
+        assert torch.equal(xr[pg.n_own:].cpu(), torch.tensor(x[halo_ids]))
+        orep = gdist.dist_sparse_gat_layer(xr, r_["W"], r_["a1"], r_["a2"], r_["b1"], r_["b2"], r_["bias"], pg, cfg, halo="replicate")
+        orep.backward(torch.tensor(dout[lo:hi], device=dev))
+        gdist.allreduce_grads(list(r_.values()))
+        assert_close(orep.detach().cpu().numpy(), ref.detach().cpu().numpy()[lo:hi], rtol=2e-6, atol_scale=1e-6, what="replicate out")
+        for k in p:
+            assert_close(r_[k].grad.cpu().numpy(), tp[k].grad.cpu().numpy(), rtol=1e-5, atol_scale=5e-6, what="replicate d" + k)
+        o16r = gdist.dist_sparse_gat_layer(xr, r_["W"], r_["a1"], r_["a2"], r_["b1"], r_["b2"], r_["bias"], pg,
+                                           ops.make_cfg(H, D, "elu", "concat", storage="bf16"), halo="replicate")
+        assert_close(o16r.detach().cpu().numpy(), ref.detach().cpu().numpy()[lo:hi], rtol=2e-2, atol_scale=2e-2, what="replicate bf16 out")
+        try:
+            gdist.dist_sparse_gat_layer(xr.clone().requires_grad_(True), r_["W"], r_["a1"], r_["a2"], r_["b1"], r_["b2"],
+                                        r_["bias"], pg, cfg, halo="replicate")
+            raise AssertionError("replicate mode accepted an input that needs a gradient")
+        except ValueError:
+            pass
         # bf16 storage: bf16 rows on the wire, same result class as the single-GPU bf16 layer
         cfg16 = ops.make_cfg(H, D, "elu", "concat", storage="bf16")
         b_ = leaves()
