@@ -1,18 +1,73 @@
-"""Unique remote source rows (halo) of one products-sized shard of a world-times larger R-MAT
-graph: what each rank receives per forward exchange and returns per backward exchange."""
+"""One products-sized shard of a world-times larger R-MAT graph, seen from rank 0 and run alone:
+  * unique remote source rows (halo): what each rank receives per forward exchange and returns per
+    backward exchange in halo="exchange" mode, and what it stores once in halo="replicate" mode;
+  * the compute time of the step in replicate mode (owned + halo rows projected locally), measured
+    in this one process with random rows standing in for the peers' input rows.  This is rank 0's
+    step without the all-reduce of the parameter gradients (a few KB)."""
+import json
 import os
 import sys
+import time
 
+import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gat_amd import synth
-dev=torch.device('cuda:0')
-n_own, e_own = synth.PRODUCTS_NODES, synth.PRODUCTS_EDGES
-for world in (2,4,8):
-    n=n_own*world
-    d,s=synth.rmat_graph(n, e_own, 4, dev, row_range=(0,n_own))
-    rem=s[(s>=n_own)]
-    u=torch.unique(rem)
-    print(world, "edges", d.numel(), "remote edge frac %.3f"%(rem.numel()/d.numel()), "n_halo", u.numel(), "halo MB fwd %.0f"%(u.numel()*288/1e6))
-    del d,s,rem,u
+from gat_amd import CSRGraph, ops, synth
+from gat_amd import dist as gdist
+from gat_amd.layers import GATHeads
+
+
+class _NoPeers:
+    """Stand-in for HaloExchange when the peers are not running: nothing to send or receive."""
+    def __init__(self, n_own, n_halo):
+        self.n_own, self.n_halo, self.n_send, self.world = n_own, n_halo, 0, 1
+
+    def gather_halo(self, table, width):
+        pass
+
+    def scatter_add_halo(self, table, width):
+        pass
+
+
+def main():
+    dev = torch.device("cuda:0")
+    n_own, e_own = synth.PRODUCTS_NODES, synth.PRODUCTS_EDGES
+    F, H, D = 100, 8, 8
+    for world in ([int(a) for a in sys.argv[1:]] or (1, 2, 4, 8)):
+        n = n_own * world
+        part = np.arange(world + 1, dtype=np.int64) * n_own
+        dst, src = synth.rmat_graph(n, e_own, 4, dev, row_range=(0, n_own))
+        cl, halo, counts = gdist.halo_plan_device(part, 0, src)
+        remote = float((src >= n_own).sum()) / src.numel()
+        n_halo = int(halo.numel())
+        g = CSRGraph.from_device_coo(dst, cl.to(torch.int64), n_own, n_own + n_halo, chunk=0)
+        del dst, src, cl
+        pg = gdist.PartitionedGraph(g, _NoPeers(n_own, n_halo), part, 0)
+        x = synth.normal((n_own + n_halo, F), 5, dev)
+        dout = synth.normal((n_own, H * D), 8, dev)
+        m = GATHeads(F, H, D, device=dev)
+        m.load(synth.glorot_layer(F, H, D, 7, dev))
+        params = list(m.parameters())
+        cfg = ops.make_cfg(H, D, "elu", "concat")
+
+        def step():
+            for p in params:
+                p.grad = None
+            gdist.dist_sparse_gat_layer(x, m.W, m.a1, m.a2, m.b1, m.b2, m.bias, pg, cfg, "replicate").backward(dout)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 10 * 1e3
+        print(json.dumps({"world": world, "entries": g.nnz, "remote_entry_frac": round(remote, 3), "n_halo": n_halo,
+                          "exchange_MB_per_direction_f32": round(n_halo * 288 / 1e6), "replicated_input_MB": round(n_halo * F * 4 / 1e6),
+                          "replicate_step_ms": round(ms, 3), "edges_per_s_per_gpu": round(g.nnz / ms * 1e3)}), flush=True)
+        del g, pg, x, dout, m
+
+
+if __name__ == "__main__":
+    main()

@@ -296,12 +296,13 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         _lib.call("gatmi_gat_bwd_csc", n_src, H, dp, ptr(graph.items_csc), len(graph.items_csc),
                   ptr(graph.split_csc) if len(graph.split_csc) else None, len(graph.split_csc),
                   ptr(graph.rowidx), ptr(graph.perm), ptr(g16 if bf16 else g), _lib.DTYPE_BF16 if bf16 else _lib.DTYPE_F32,
-                  ptr(stats), ptr(feat), ptr(f2), None, None, None,
+                  ptr(stats), ptr(feat), ptr(f2), ptr(df1) if replicate else None, ptr(a1p) if replicate else None,
+                  ptr(a2p) if replicate else None,
                   cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dfeat), ptr(df2), ptr(ws2), st)
         if replicate:
-            # this rank's share of every sum over sources, on owned + halo rows; the all-reduce of the
-            # parameter gradients adds the shares of the other ranks
-            _lib.call("gatmi_gat_bwd_finalize", n_src, H, dp, ptr(df1), ptr(df2), ptr(a1p), ptr(a2p), ptr(dfeat), st)
+            # dfeat already holds dWh (the logit terms df1.a1 + df2.a2 were added by the sweep): this rank's
+            # share of every sum over sources, on owned + halo rows; the all-reduce of the parameter
+            # gradients adds the shares of the other ranks
             _, dW, da1, da2, db1, db2, _ = ops._project_backward(x, Wp, None, feat, dfeat, df1, df2, g, cfg, False)
             db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None
             return None, dW, da1, da2, db1, db2, db, None, None, None
