@@ -38,12 +38,6 @@ struct DenseFwdArgs {
     uint64_t seed;
 };
 
-// coefficient-dropout factor of entry (i, j) of graph b, head hg: 0 or 1/keep (utils/layers.py:20)
-__device__ __forceinline__ float coef_drop_scale(uint64_t seed, int64_t b, int N, int H, int i, int j, int hg, float keep) {
-    const uint64_t idx = (((uint64_t)b * N + (uint64_t)i) * N + (uint64_t)j) * H + hg;
-    return keep_mask(seed, idx, keep) ? 1.0f / keep : 0.f;
-}
-
 // How the four waves of a block split the work: heads first (each wave keeps only HPW heads'
 // accumulators, so registers stay low and many blocks fit a CU), 16-row tiles with what is left.
 template <int H>

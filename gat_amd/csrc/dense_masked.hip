@@ -1,0 +1,595 @@
+// Batched dense masked graph attention for SPARSE masks (gfx950): the layer of dense_attn.hip,
+//     alpha_ij = softmax_j( LeakyReLU(f1[i,h] + f2[j,h]) + bias_mat[b,i,j] ),  out_i = sum_j alpha_ij Wh_j,
+// computed by visiting only the entries of bias_mat that can contribute.  adj_to_bias masks
+// (utils/process.py:14-25) are 0 on a graph's edges and -1e9 elsewhere; at a density of 10 % nine
+// tenths of the (i, j, head) work of the matrix-core kernels multiplies zeros.  Here a wave reads
+// the mask rows (coalesced, once from HBM), compacts the contributing column indices into LDS with
+// wave ballots, and then runs the row kernels of gat_sparse.hip's design on the compacted lists:
+// G = hd/4 lanes per row, online softmax four neighbours at a time, Wh rows gathered from L2 (a
+// graph's Wh is a few tens of KB).
+//
+// Which entries contribute: entry (i, j) is visited iff bias_mat[i,j] > max_j' bias_mat[i,j'] - 1e6.
+// An entry below that line has a softmax numerator exp(logit_ij - 1e6 - (row maximum)) = 0 in fp32
+// (and in fp64) for any logits below 4e5, so skipping it changes nothing; the bias values of the
+// visited entries are added to the logits as in the dense kernels, so soft masks are exact too,
+// and a row whose entries are all -1e9 keeps all of them (uniform attention, as the dense kernels
+// give).
+//
+// In training the forward kernel also writes which entries it visited: one bit per entry, W =
+// ceil(N/32) + 1 words per row, the last word holding bit 0 = "some visited entry of this row has a
+// non-zero bias".  The backward pass never reads the fp32 mask of an adj_to_bias batch again: block
+// (graph b, 32 source columns) reads one word per destination row, turns the 32 bit columns into
+// row-index lists in LDS with 32 wave ballots per 64 rows (lists of a column are filled in row
+// order, so every sum runs in a fixed order), and G lanes per column walk the lists like
+// gat_bwd_csc_kernel walks CSC rows, fetching a bias value only for rows flagged as above.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "device_common.h"
+
+namespace gatmi {
+
+constexpr float kMaskCutoffFwd = 1.0e6f;
+constexpr int kListBytesPerWave = 4096;   // forward: LDS for the compacted lists of one wave's rows
+constexpr int kBwdCols = 32;              // backward: source columns per block = bits of one word
+constexpr int kBwdChunks = 8;             // backward: 64-row chunks listed per pass
+constexpr int kMaskedMaxN = 32767;        // list entries are 15-bit node ids + 1 flag bit
+
+struct MaskedFwdArgs {
+    int64_t B;
+    int N;
+    const float *Wh, *f1, *f2, *bias_mat, *bias, *resid;
+    float *out, *agg, *pos, *lse, *q;
+    uint32_t *present;         // [B*N, W] visited-entry bits + flag word, or nullptr
+    int activation;
+    float slope, coef_keep, feat_keep;
+    uint64_t seed;
+};
+
+struct MRowState {
+    float m, s, q;
+    float4 acc, pos;
+};
+
+#ifndef GATMI_MASK_BATCH
+#define GATMI_MASK_BATCH 8
+#endif
+#ifndef GATMI_MASK_MINBLOCKS
+#define GATMI_MASK_MINBLOCKS 4
+#endif
+constexpr int kBatch = GATMI_MASK_BATCH;  // list entries per step of a row / column walk (independent gathers in flight)
+
+// ids[t] = t-th of kBatch consecutive uint16 list entries at lp (16-byte aligned)
+__device__ __forceinline__ void load_ids(const uint16_t *lp, int (&ids)[kBatch]) {
+    static_assert(kBatch == 4 || kBatch == 8, "four or eight 16-bit ids per step");
+    uint32_t w[4];
+    if constexpr (kBatch == 8) {
+        const uint4 packed = *reinterpret_cast<const uint4 *>(lp);
+        w[0] = packed.x; w[1] = packed.y; w[2] = packed.z; w[3] = packed.w;
+    } else {
+        const uint2 packed = *reinterpret_cast<const uint2 *>(lp);
+        w[0] = packed.x; w[1] = packed.y; w[2] = w[3] = 0;
+    }
+#pragma unroll
+    for (int t = 0; t < kBatch; ++t) ids[t] = (w[t >> 1] >> (16 * (t & 1))) & 0xffff;
+}
+
+// One batch of up to kBatch listed sources of one destination row.
+// whb / f2b: this lane's float4 column of the graph's Wh rows / this lane's head of its f2 rows, so the
+// gathers need one 32-bit multiply-add per address (row ids of one graph are below 2^15).
+template <int G, int LPH, bool SAVE, bool DROP>
+__device__ __forceinline__ void masked_fwd_batch(MRowState &st, const MaskedFwdArgs &a, const uint16_t *lp, int nvalid,
+                                                 int64_t b, int i, const float *bm, const float *whb, const float *f2b,
+                                                 float f1v, int sub, int head) {
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    constexpr int U = kBatch;
+    const int N = a.N;
+    int j[U];
+    float z[U], e[U];
+    float4 v[U];
+    load_ids(lp, j);
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        if (t >= nvalid) j[t] = j[0];
+        z[t] = f1v + f2b[(uint32_t)j[t] * H];
+        v[t] = *reinterpret_cast<const float4 *>(whb + (uint32_t)j[t] * HD);
+        e[t] = bm[(uint32_t)j[t]];
+    }
+    float mn = st.m;
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        e[t] = t < nvalid ? leaky(z[t], a.slope) + e[t] : -INFINITY;
+        mn = fmaxf(mn, e[t]);
+    }
+    const float sc = exp_neg(st.m - mn);
+    float bs = 0.f, bq = 0.f;
+    float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f), bpos = bacc;
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        const float p = exp_neg(e[t] - mn);
+        bs += p;
+        float pa = p;
+        float4 vv = v[t];
+        if (DROP) {
+            if (a.coef_keep < 1.f) pa = p * coef_drop_scale(a.seed, b, N, H, i, j[t], head, a.coef_keep);
+            if (a.feat_keep < 1.f) vv = drop_feat(vv, a.seed, b * N + j[t], HD, sub * 4, a.feat_keep);
+        }
+        bacc = f4_fma(pa, vv, bacc);
+        if (SAVE) {
+            const bool ps = z[t] > 0.f;
+            bq += ps ? p : 0.f;
+            bpos = f4_fma(ps ? pa : 0.f, vv, bpos);
+        }
+    }
+    st.s = fmaf(st.s, sc, bs);
+    st.acc = f4_fma(sc, st.acc, bacc);
+    if (SAVE) {
+        st.q = fmaf(st.q, sc, bq);
+        st.pos = f4_fma(sc, st.pos, bpos);
+    }
+    st.m = mn;
+}
+
+// Block (graph b, 4 * 64/G destination rows): wave w owns rows base + w*RPW .. + RPW-1.
+template <int G, int LPH, bool SAVE, bool DROP>
+__global__ __launch_bounds__(256, GATMI_MASK_MINBLOCKS) void dense_masked_fwd_kernel(MaskedFwdArgs a) {
+    constexpr int RPW = 64 / G;
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    constexpr int LC = kListBytesPerWave / 2 / RPW;      // list capacity per row = mask entries compacted per pass
+    __shared__ __attribute__((aligned(16))) uint16_t lists[4][RPW][LC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % G, grp = lane / G;
+    const int head = sub / LPH;
+    const int N = a.N;
+    const int64_t b = blockIdx.x;
+    const int row0 = (blockIdx.y * 4 + wave) * RPW;
+    if (row0 >= N) return;                               // whole wave past the graph (no block-wide barrier below)
+    const int i = min(row0 + grp, N - 1);                // this lane group's destination row
+    const bool row_ok = row0 + grp < N;
+    const float *bmat = a.bias_mat + b * N * (int64_t)N;
+    const float f1v = a.f1[(b * N + i) * H + head];
+    const int W = (N + 31) / 32 + 1;                     // words per row of a.present
+
+    MRowState st;
+    st.m = -INFINITY;
+    st.s = st.q = 0.f;
+    st.acc = st.pos = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *bm_own = bmat + (int64_t)i * N;
+    const float *whb = a.Wh + b * N * (int64_t)HD + sub * 4;
+    const float *f2b = a.f2 + b * N * (int64_t)H + head;
+    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    constexpr int U = 2;                                 // 16-byte loads per lane and row in the register-resident path
+    if ((N & 3) == 0 && N <= 256 * U && N <= LC) {
+        // Small graphs: every mask row of the wave is loaded once, 16 bytes per lane and all loads in
+        // flight together; row maxima and compaction work from registers.
+        float4 mv[RPW][U];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const float *bm = bmat + (int64_t)min(row0 + rr, N - 1) * N;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                mv[rr][u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                if (N - 256 * u > 64) {                    // a 256-column block: four columns per lane
+                    const int j = 4 * lane + 256 * u;
+                    if (j < N) mv[rr][u] = *reinterpret_cast<const float4 *>(bm + j);
+                } else if (256 * u + lane < N) {           // a tail of at most 64 columns: one per lane, in .x
+                    mv[rr][u].x = bm[256 * u + lane];
+                }
+            }
+        }
+        int mycnt = 0;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < U; ++u) mx = fmaxf(fmaxf(mx, fmaxf(mv[rr][u].x, mv[rr][u].y)), fmaxf(mv[rr][u].z, mv[rr][u].w));
+#pragma unroll
+            for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            const float cut = mx - kMaskCutoffFwd;
+            int cnt = 0;
+            bool nonzero = false;
+            uint32_t *prow = a.present ? a.present + (b * N + min(row0 + rr, N - 1)) * (int64_t)W : nullptr;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (256 * u >= N) break;
+                if (N - 256 * u <= 64) {                   // tail: one ballot covers it, and is its two bit words
+                    const bool present = mv[rr][u].x > cut;
+                    const uint64_t bal = __ballot(present);
+                    if (present) lists[wave][rr][cnt + __popcll(bal & lt_mask)] = (uint16_t)(256 * u + lane);
+                    cnt += __popcll(bal);
+                    nonzero |= present && mv[rr][u].x != 0.f;
+                    if (prow && lane < 2 && 8 * u + lane < W - 1) prow[8 * u + lane] = (uint32_t)(bal >> (32 * lane));
+                    break;
+                }
+                const float comp[4] = {mv[rr][u].x, mv[rr][u].y, mv[rr][u].z, mv[rr][u].w};
+                uint32_t nib = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const bool present = comp[t] > cut;
+                    const uint64_t bal = __ballot(present);
+                    if (present) lists[wave][rr][cnt + __popcll(bal & lt_mask)] = (uint16_t)(4 * lane + 256 * u + t);
+                    cnt += __popcll(bal);
+                    nib |= present ? (1u << t) : 0u;
+                    nonzero |= present && comp[t] != 0.f;
+                }
+                if (prow) {                               // word 8u + lane/8 holds columns 4*lane+256u .. of 8 adjacent lanes
+                    uint32_t w = nib << (4 * (lane & 7));
+                    w |= __shfl_xor(w, 1, 64);
+                    w |= __shfl_xor(w, 2, 64);
+                    w |= __shfl_xor(w, 4, 64);
+                    const int wi = 8 * u + (lane >> 3);
+                    if ((lane & 7) == 0 && wi < W - 1) prow[wi] = w;
+                }
+            }
+            const uint64_t nzb = __ballot(nonzero);
+            if (prow && lane == 0) prow[W - 1] = nzb != 0 ? 1u : 0u;
+            if (rr == grp) mycnt = cnt;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (row_ok) {
+            const uint16_t *lp = lists[wave][grp];
+            for (int k = 0; k < mycnt; k += kBatch)
+                masked_fwd_batch<G, LPH, SAVE, DROP>(st, a, lp + k, min(kBatch, mycnt - k), b, i, bm_own, whb, f2b, f1v, sub, head);
+        }
+    } else {
+        // General sizes: row maxima first (one row of the wave at a time with all 64 lanes), then the
+        // rows are compacted and consumed in passes of LC mask entries; the second read hits L2.
+        float bmax = -INFINITY;
+        for (int rr = 0; rr < RPW; ++rr) {
+            const float *bm = bmat + (int64_t)min(row0 + rr, N - 1) * N;
+            float mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY, mx3 = -INFINITY;
+            int j = lane;
+            for (; j + 192 < N; j += 256) {                  // four independent loads in flight
+                mx0 = fmaxf(mx0, bm[j]); mx1 = fmaxf(mx1, bm[j + 64]); mx2 = fmaxf(mx2, bm[j + 128]); mx3 = fmaxf(mx3, bm[j + 192]);
+            }
+            for (; j < N; j += 64) mx0 = fmaxf(mx0, bm[j]);
+            float mx = fmaxf(fmaxf(mx0, mx1), fmaxf(mx2, mx3));
+#pragma unroll
+            for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            if (rr == grp) bmax = mx;
+        }
+        for (int seg0 = 0; seg0 < N; seg0 += LC) {
+            const int seg_end = min(N, seg0 + LC);
+            int mycnt = 0;
+            for (int rr = 0; rr < RPW; ++rr) {               // compact the contributing columns of row row0 + rr
+                const float *bm = bmat + (int64_t)min(row0 + rr, N - 1) * N;
+                const float cut = __shfl(bmax, rr * G, 64) - kMaskCutoffFwd;
+                uint32_t *prow = a.present ? a.present + (b * N + min(row0 + rr, N - 1)) * (int64_t)W : nullptr;
+                int cnt = 0;
+                uint64_t nzb = 0;
+                for (int j0 = seg0; j0 < seg_end; j0 += 64) {   // seg0 and LC are multiples of 64: a ballot is two words
+                    const int j = j0 + lane;
+                    const float bvj = j < seg_end ? bm[j] : -INFINITY;
+                    const bool present = bvj > cut;
+                    const uint64_t bal = __ballot(present);
+                    if (present) lists[wave][rr][cnt + __popcll(bal & lt_mask)] = (uint16_t)j;
+                    cnt += __popcll(bal);
+                    nzb |= __ballot(present && bvj != 0.f);
+                    if (prow && lane < 2 && (j0 >> 5) + lane < W - 1) prow[(j0 >> 5) + lane] = (uint32_t)(bal >> (32 * lane));
+                }
+                if (prow && lane == 0) {                        // flag word: OR over the passes
+                    const uint32_t f = nzb != 0 ? 1u : 0u;
+                    prow[W - 1] = seg0 == 0 ? f : (prow[W - 1] | f);
+                }
+                if (rr == grp) mycnt = cnt;
+            }
+            // the lists are written and read by this wave only; its lanes run in lockstep
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (row_ok) {
+                const uint16_t *lp = lists[wave][grp];
+                for (int k = 0; k < mycnt; k += kBatch)
+                    masked_fwd_batch<G, LPH, SAVE, DROP>(st, a, lp + k, min(kBatch, mycnt - k), b, i, bm_own, whb, f2b, f1v, sub, head);
+            }
+            __builtin_amdgcn_wave_barrier();                 // all reads done before the next pass overwrites the lists
+        }
+    }
+    if (!row_ok) return;
+    const int64_t row = b * N + i;
+    const bool empty = !(st.s > 0.f);
+    const float inv = empty ? 0.f : 1.0f / st.s;
+    const float4 ag = f4_scale(inv, st.acc);
+    if (SAVE) {
+        *reinterpret_cast<float4 *>(a.agg + row * HD + sub * 4) = ag;
+        *reinterpret_cast<float4 *>(a.pos + row * HD + sub * 4) = f4_scale(inv, st.pos);
+        if (sub % LPH == 0) {
+            a.lse[row * H + head] = empty ? 0.f : st.m + logf(st.s);
+            a.q[row * H + head] = st.q * inv;
+        }
+    }
+    float4 r = ag;
+    if (a.bias) r = f4_add(r, *reinterpret_cast<const float4 *>(a.bias + sub * 4));
+    if (a.resid) r = f4_add(r, *reinterpret_cast<const float4 *>(a.resid + row * HD + sub * 4));
+    if (a.activation == GATMI_ACT_ELU) r = make_float4(elu_f(r.x), elu_f(r.y), elu_f(r.z), elu_f(r.w));
+    *reinterpret_cast<float4 *>(a.out + row * HD + sub * 4) = r;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------
+struct MaskedBwdArgs {
+    int64_t B;
+    int N;
+    const float *g, *stats, *Wh, *f2, *bias_mat, *df1, *a1, *a2;
+    const uint32_t *present;   // [B*N, W] bits written by the forward kernel
+    float *dWh, *df2;
+    float slope, coef_keep, feat_keep;
+    uint64_t seed;
+};
+
+struct MSrcState {
+    float4 acc;
+    float df2;
+};
+
+// gb / statb / bmcol: this lane's float4 column of the graph's g rows, its head's first statistic and
+// column jcol of the graph's mask, addressed by 32-bit row offsets.
+template <int G, int LPH, bool DROP>
+__device__ __forceinline__ void masked_bwd_batch(MSrcState &st, const MaskedBwdArgs &a, const uint16_t *lp, int nvalid,
+                                                 int64_t b, int jcol, const float *gb, const float *statb, const float *bmcol,
+                                                 float f2v, float4 whj, int sub, int head) {
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    constexpr int U = kBatch;
+    const int N = a.N;
+    int i[U];
+    float4 gv[U];
+    float f1v[U], lsev[U], cv[U], bv[U];
+    load_ids(lp, i);                                  // entries: row id | (needs its bias value) << 15
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        if (t >= nvalid) i[t] = i[0];
+        const bool soft = i[t] & 0x8000;
+        i[t] &= 0x7fff;
+        gv[t] = *reinterpret_cast<const float4 *>(gb + (uint32_t)i[t] * HD);
+        const float *s = statb + (uint32_t)i[t] * (3 * H);
+        f1v[t] = s[0];
+        lsev[t] = s[H];
+        cv[t] = s[2 * H];
+        bv[t] = soft ? bmcol[(uint32_t)i[t] * (uint32_t)N] : 0.f;
+    }
+    float bdf2 = 0.f;
+    float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        const float z = f1v[t] + f2v;
+        float alpha = exp_neg(leaky(z, a.slope) + bv[t] - lsev[t]);
+        if (t >= nvalid) alpha = 0.f;
+        float dalpha = group_sum<LPH>(dot4(gv[t], whj));
+        float aa = alpha;
+        if (DROP) {
+            if (a.coef_keep < 1.f) {
+                const float mk = coef_drop_scale(a.seed, b, N, H, i[t], jcol, head, a.coef_keep);
+                aa = alpha * mk;
+                dalpha *= mk;
+            }
+        }
+        bdf2 += alpha * (dalpha - cv[t]) * (z > 0.f ? 1.f : a.slope);
+        bacc = f4_fma(aa, gv[t], bacc);
+    }
+    st.acc = f4_add(st.acc, bacc);
+    st.df2 += bdf2;
+}
+
+template <int G, int LPH, bool DROP>
+__global__ __launch_bounds__(256, GATMI_MASK_MINBLOCKS) void dense_masked_bwd_kernel(MaskedBwdArgs a, int n_chunks) {
+    constexpr int RPW = 64 / G;
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    constexpr int GB = 4 * RPW;                       // column groups per block
+    constexpr int PASSES = kBwdCols / GB;             // columns per group
+    static_assert(kBwdCols % GB == 0 && PASSES >= 1 && kBwdCols == 32, "32 columns per block: the bits of one word");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint16_t *lists = reinterpret_cast<uint16_t *>(smem_raw);                                  // [col][n_chunks * 64]
+    int *counts = reinterpret_cast<int *>(smem_raw + (size_t)kBwdCols * n_chunks * 64 * 2);     // [col][kBwdChunks + 1]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % G, grp = lane / G;
+    const int head = sub / LPH;
+    const int N = a.N;
+    const int W = (N + 31) / 32 + 1;
+    const int64_t b = blockIdx.x;
+    const int c0 = blockIdx.y * kBwdCols;
+    const int gidx = wave * RPW + grp;                // this lane group's index in the block
+    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const float *gb = a.g + b * N * (int64_t)HD + sub * 4;
+    const float *statb = a.stats + b * N * (int64_t)(3 * H) + head;
+
+    MSrcState st[PASSES];
+    float f2v[PASSES];
+    float4 whj[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int jcol = min(c0 + p * GB + gidx, N - 1);
+        st[p].acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        st[p].df2 = 0.f;
+        f2v[p] = a.f2[(b * N + jcol) * H + head];
+        whj[p] = *reinterpret_cast<const float4 *>(a.Wh + (b * N + jcol) * (int64_t)HD + sub * 4);
+        if (DROP) {
+            if (a.feat_keep < 1.f) whj[p] = drop_feat(whj[p], a.seed, b * N + jcol, HD, sub * 4, a.feat_keep);
+        }
+    }
+
+    const int seg_rows = n_chunks * 64;               // capacity of one column's list
+    for (int seg0 = 0; seg0 < N; seg0 += seg_rows) {
+        __syncthreads();                              // the previous pass has finished reading the lists
+        // This wave's chunks: c = wave and c = wave + 4 (n_chunks <= 8); lane = destination row.
+        uint32_t word[2] = {0u, 0u};
+        uint16_t entry[2] = {0, 0};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = wave + 4 * q;
+            const int i = seg0 + 64 * c + lane;
+            if (c < n_chunks && i < N) {
+                const uint32_t *prow = a.present + (b * N + i) * (int64_t)W;
+                word[q] = prow[blockIdx.y];
+                entry[q] = (uint16_t)(i | ((prow[W - 1] & 1u) << 15));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                 // entries per (column, chunk)
+            const int c = wave + 4 * q;
+            if (c >= n_chunks) continue;
+            int mycount = 0;
+#pragma unroll
+            for (int col = 0; col < kBwdCols; ++col) {
+                const int n = __popcll(__ballot((word[q] >> col) & 1u));
+                if (lane == col) mycount = n;
+            }
+            if (lane < kBwdCols) counts[lane * (kBwdChunks + 1) + c] = mycount;
+        }
+        __syncthreads();
+        if (threadIdx.x < kBwdCols) {                 // exclusive prefix over the chunks of a column; slot kBwdChunks = total
+            int run = 0;
+            for (int c = 0; c < n_chunks; ++c) {
+                const int n = counts[threadIdx.x * (kBwdChunks + 1) + c];
+                counts[threadIdx.x * (kBwdChunks + 1) + c] = run;
+                run += n;
+            }
+            counts[threadIdx.x * (kBwdChunks + 1) + kBwdChunks] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                 // fill: a column's list is contiguous and sorted by row
+            const int c = wave + 4 * q;
+            if (c >= n_chunks) continue;
+#pragma unroll
+            for (int col = 0; col < kBwdCols; ++col) {
+                const bool bit = (word[q] >> col) & 1u;
+                const uint64_t bal = __ballot(bit);
+                if (bit) lists[(size_t)col * seg_rows + counts[col * (kBwdChunks + 1) + c] + __popcll(bal & lt_mask)] = entry[q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int cl = p * GB + gidx;             // column within the block
+            const int jcol = c0 + cl;
+            if (jcol < N) {
+                const int cnt = counts[cl * (kBwdChunks + 1) + kBwdChunks];
+                const uint16_t *lp = lists + (size_t)cl * seg_rows;
+                const float *bmcol = a.bias_mat + b * N * (int64_t)N + jcol;
+                for (int k = 0; k < cnt; k += kBatch)
+                    masked_bwd_batch<G, LPH, DROP>(st[p], a, lp + k, min(kBatch, cnt - k), b, jcol, gb, statb, bmcol, f2v[p], whj[p], sub, head);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int jcol = c0 + p * GB + gidx;
+        if (jcol >= N) continue;
+        const int64_t j = b * N + jcol;
+        float4 r = st[p].acc;
+        if (DROP) {
+            if (a.feat_keep < 1.f) r = drop_feat(r, a.seed, j, HD, sub * 4, a.feat_keep);
+        }
+        if (a.a1) {
+            const float d1 = a.df1[j * H + head];
+            r = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + sub * 4), r);
+            r = f4_fma(st[p].df2, *reinterpret_cast<const float4 *>(a.a2 + sub * 4), r);
+        }
+        *reinterpret_cast<float4 *>(a.dWh + j * HD + sub * 4) = r;
+        if (sub % LPH == 0) a.df2[j * H + head] = st[p].df2;
+    }
+}
+
+// (G, LPH) pairs built: rows of 32..256 floats (narrower rows leave most of a wave idle in the
+// compaction; those shapes stay with the matrix-core kernels)
+#define GATMI_MASKED_SHAPES(X) X(8, 1) X(8, 2) X(8, 4) X(8, 8) X(16, 1) X(16, 2) X(16, 4) X(16, 8) X(16, 16) \
+    X(32, 1) X(32, 2) X(32, 4) X(32, 8) X(32, 16) X(32, 32) X(64, 1) X(64, 2) X(64, 4) X(64, 8) X(64, 16) X(64, 32) X(64, 64)
+
+}  // namespace gatmi
+
+using namespace gatmi;
+
+static int masked_check(int64_t B, int32_t N, int32_t H, int32_t dp, int *G, int *LPH, const char *name) {
+    int rc = check_shape(H, dp, G, LPH);
+    if (rc) return rc;
+    GATMI_REQUIRE(B >= 0 && N >= 0, GATMI_EINVAL, "%s: negative size", name);
+    GATMI_REQUIRE(*G >= 8, GATMI_EUNSUPPORTED, "%s: rows of H*dp = %d floats are too narrow for the list kernels (>= 32)", name, 4 * *G);
+    GATMI_REQUIRE(N <= kMaskedMaxN, GATMI_EUNSUPPORTED, "%s: N = %d does not fit the 15-bit node ids of the lists", name, N);
+    GATMI_REQUIRE(B <= 0x7fffffff && (int64_t)(N + 3) / 4 <= 65535, GATMI_ERANGE, "%s: too large for one launch", name);
+    return GATMI_OK;
+}
+
+extern "C" size_t gatmi_dense_mask_words(int32_t N) { return N < 0 ? 0 : (size_t)(N + 31) / 32 + 1; }
+
+extern "C" int gatmi_dense_attn_fwd_masked(int64_t B, int32_t N, int32_t H, int32_t dp,
+                                           const float *Wh, const float *f1, const float *f2, const float *bias_mat,
+                                           const float *bias, const float *resid, int32_t activation, float slope,
+                                           float coef_keep, float feat_keep, uint64_t seed,
+                                           float *out, float *agg, float *pos, float *lse, float *q,
+                                           uint32_t *present, void *stream) {
+    int G, LPH;
+    int rc = masked_check(B, N, H, dp, &G, &LPH, "dense_attn_fwd_masked");
+    if (rc) return rc;
+    if (B == 0 || N == 0) return GATMI_OK;
+    GATMI_REQUIRE(Wh && f1 && f2 && bias_mat && out, GATMI_EINVAL, "dense_attn_fwd_masked: null pointer");
+    GATMI_REQUIRE(activation == GATMI_ACT_IDENTITY || activation == GATMI_ACT_ELU, GATMI_EUNSUPPORTED, "dense_attn_fwd_masked: activation %d", activation);
+    const bool save = agg || pos || lse || q;
+    GATMI_REQUIRE(!save || (agg && pos && lse && q), GATMI_EINVAL, "dense_attn_fwd_masked: agg, pos, lse, q must be given together");
+    GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "dense_attn_fwd_masked: keep probabilities must be in (0,1]");
+    const bool drop = coef_keep < 1.f || feat_keep < 1.f;
+    GATMI_REQUIRE(!drop || save, GATMI_EINVAL, "dense_attn_fwd_masked: dropout is a training-time option and needs agg, pos, lse, q");
+    GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(out); GATMI_REQUIRE_ALIGNED(bias); GATMI_REQUIRE_ALIGNED(resid);
+    GATMI_REQUIRE_ALIGNED(bias_mat);
+    GATMI_REQUIRE_ALIGNED(agg); GATMI_REQUIRE_ALIGNED(pos);
+    MaskedFwdArgs a;
+    a.B = B; a.N = N; a.Wh = Wh; a.f1 = f1; a.f2 = f2; a.bias_mat = bias_mat; a.bias = bias; a.resid = resid;
+    a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.activation = activation; a.slope = slope;
+    a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.present = present;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rows_per_block = 4 * (64 / G);
+    const dim3 grid((unsigned)B, (unsigned)((N + rows_per_block - 1) / rows_per_block));
+#define X(gg, ll)                                                                                                 \
+    if (G == gg && LPH == ll) {                                                                                   \
+        if (drop) hipLaunchKernelGGL((dense_masked_fwd_kernel<gg, ll, true, true>), grid, dim3(256), 0, st, a);    \
+        else if (save) hipLaunchKernelGGL((dense_masked_fwd_kernel<gg, ll, true, false>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((dense_masked_fwd_kernel<gg, ll, false, false>), grid, dim3(256), 0, st, a);       \
+        GATMI_LAUNCH_CHECK("dense_attn_fwd_masked");                                                              \
+        return GATMI_OK;                                                                                          \
+    }
+    GATMI_MASKED_SHAPES(X)
+#undef X
+    return fail(GATMI_EUNSUPPORTED, "dense_attn_fwd_masked: no kernel for H=%d dp=%d", H, dp);
+}
+
+extern "C" int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int32_t dp,
+                                           const float *g, const float *stats, const float *Wh, const float *f2,
+                                           const float *bias_mat, const float *df1, const float *a1, const float *a2,
+                                           const uint32_t *present,
+                                           float slope, float coef_keep, float feat_keep, uint64_t seed,
+                                           float *dWh, float *df2, void *stream) {
+    int G, LPH;
+    int rc = masked_check(B, N, H, dp, &G, &LPH, "dense_attn_bwd_masked");
+    if (rc) return rc;
+    if (B == 0 || N == 0) return GATMI_OK;
+    GATMI_REQUIRE(g && stats && Wh && f2 && bias_mat && present && dWh && df2, GATMI_EINVAL, "dense_attn_bwd_masked: null pointer");
+    GATMI_REQUIRE((a1 == nullptr) == (a2 == nullptr) && (!a1 || df1), GATMI_EINVAL, "dense_attn_bwd_masked: a1, a2 and df1 go together");
+    GATMI_REQUIRE_ALIGNED(g); GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(dWh); GATMI_REQUIRE_ALIGNED(a1); GATMI_REQUIRE_ALIGNED(a2);
+    GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "dense_attn_bwd_masked: keep probabilities must be in (0,1]");
+    const bool drop = coef_keep < 1.f || feat_keep < 1.f;
+    MaskedBwdArgs a;
+    a.B = B; a.N = N; a.g = g; a.stats = stats; a.Wh = Wh; a.f2 = f2; a.bias_mat = bias_mat; a.df1 = df1; a.a1 = a1; a.a2 = a2;
+    a.dWh = dWh; a.df2 = df2; a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.present = present;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)B, (unsigned)((N + kBwdCols - 1) / kBwdCols));
+    const int n_chunks = std::min(kBwdChunks, (N + 63) / 64);
+    const size_t lds = (size_t)kBwdCols * (n_chunks * 64 * sizeof(uint16_t) + (kBwdChunks + 1) * sizeof(int));
+#define X(gg, ll)                                                                                          \
+    if (G == gg && LPH == ll) {                                                                            \
+        if (drop) hipLaunchKernelGGL((dense_masked_bwd_kernel<gg, ll, true>), grid, dim3(256), lds, st, a, n_chunks);   \
+        else hipLaunchKernelGGL((dense_masked_bwd_kernel<gg, ll, false>), grid, dim3(256), lds, st, a, n_chunks);       \
+        GATMI_LAUNCH_CHECK("dense_attn_bwd_masked");                                                       \
+        return GATMI_OK;                                                                                   \
+    }
+    GATMI_MASKED_SHAPES(X)
+#undef X
+    return fail(GATMI_EUNSUPPORTED, "dense_attn_bwd_masked: no kernel for H=%d dp=%d", H, dp);
+}

@@ -51,6 +51,21 @@ __device__ __forceinline__ float drop_feat1(float v, uint64_t seed, int64_t j, i
     return keep_mask(seed ^ kFeatSeedSalt, (uint64_t)j * (uint64_t)hd + (uint64_t)c, keep) ? v / keep : 0.f;
 }
 
+// coefficient-dropout factor of entry (i, j) of graph b, head hg of a dense [B, N, N] batch:
+// 0 or 1/keep (utils/layers.py:20)
+__device__ __forceinline__ float coef_drop_scale(uint64_t seed, int64_t b, int N, int H, int i, int j, int hg, float keep) {
+    const uint64_t idx = (((uint64_t)b * N + (uint64_t)i) * N + (uint64_t)j) * H + hg;
+    return keep_mask(seed, idx, keep) ? 1.0f / keep : 0.f;
+}
+
+// float4 arithmetic of the row kernels (one float4 of a feature row per lane)
+__device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 y) {
+    return make_float4(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z), fmaf(a, x.w, y.w));
+}
+__device__ __forceinline__ float4 f4_scale(float a, float4 x) { return make_float4(a * x.x, a * x.y, a * x.z, a * x.w); }
+__device__ __forceinline__ float4 f4_add(float4 x, float4 y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); }
+__device__ __forceinline__ float dot4(float4 x, float4 y) { return fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, x.w * y.w))); }
+
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
 
 // derivative of ELU written in terms of its OUTPUT y: 1 for y > 0, y + 1 (= exp(x)) otherwise

@@ -41,13 +41,6 @@ struct FwdArgs {
     uint64_t seed;
 };
 
-__device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 y) {
-    return make_float4(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z), fmaf(a, x.w, y.w));
-}
-__device__ __forceinline__ float4 f4_scale(float a, float4 x) { return make_float4(a * x.x, a * x.y, a * x.z, a * x.w); }
-__device__ __forceinline__ float4 f4_add(float4 x, float4 y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); }
-__device__ __forceinline__ float dot4(float4 x, float4 y) { return fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, x.w * y.w))); }
-
 struct RowState {
     float m, s, q;
     float4 acc, pos;

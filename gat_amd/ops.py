@@ -50,7 +50,7 @@ def _f32(t):
 
 
 class _Cfg:
-    __slots__ = ("H", "D", "dp", "activation", "reduce", "slope", "coef_keep", "feat_keep", "seed", "storage")
+    __slots__ = ("H", "D", "dp", "activation", "reduce", "slope", "coef_keep", "feat_keep", "seed", "storage", "mask_path")
 
 
 def _new(shape, like, dtype=torch.float32):
@@ -206,6 +206,47 @@ class SparseGATLayerFn(torch.autograd.Function):
         return dx, dW, da1, da2, db1, db2, db, dWr, dbr, None, None
 
 
+MASK_LIST_DENSITY = 0.35      # the list kernels win below about a third of the entries contributing
+_density_cache = {}
+
+
+def _mask_density(bias_mat):
+    """Fraction of mask entries that can contribute (within 1e6 of their row's maximum), estimated on
+    the first graphs of the batch and remembered per tensor version.  None while a HIP graph is being
+    captured and nothing is remembered (the estimate needs a device-to-host copy)."""
+    key = (bias_mat.data_ptr(), tuple(bias_mat.shape), bias_mat._version)
+    d = _density_cache.get(key)
+    if d is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        sample = bias_mat[:max(1, min(bias_mat.shape[0], (1 << 22) // max(1, bias_mat.shape[1] * bias_mat.shape[2])))]
+        d = float((sample > sample.amax(-1, keepdim=True) - 1.0e6).float().mean())
+        if len(_density_cache) > 64:
+            _density_cache.clear()
+        _density_cache[key] = d
+    return d
+
+
+# (heads, padded width) pairs the matrix-core kernels are built for (GATMI_DENSE_SHAPES in dense_attn.hip)
+_MFMA_SHAPES = {(8, 8), (4, 8), (2, 8), (1, 8), (1, 4), (2, 4), (4, 4), (8, 4), (1, 16), (2, 16), (4, 16), (1, 32), (2, 32), (1, 64)}
+
+
+def _use_mask_lists(cfg, bias_mat):
+    """Pick the kernels for a [B,N,N] mask: compacted lists for sparse masks (and for rows wider than
+    the matrix-core kernels are built for), matrix cores otherwise."""
+    ok = cfg.H * cfg.dp >= 32 and bias_mat.shape[1] <= 32767
+    if cfg.mask_path == "lists":
+        if not ok:
+            raise ValueError("mask_path='lists' needs heads * padded width >= 32 and N <= 32767")
+        return True
+    if cfg.mask_path == "dense" or not ok:
+        return False
+    if (cfg.H, cfg.dp) not in _MFMA_SHAPES:
+        return True
+    d = _mask_density(bias_mat)
+    return d is not None and d <= MASK_LIST_DENSITY
+
+
 class DenseGATLayerFn(torch.autograd.Function):
     """Same layer on [B, N, F] inputs with an additive [B, N, N] mask (utils/layers.py:6-34)."""
 
@@ -232,11 +273,20 @@ class DenseGATLayerFn(torch.autograd.Function):
         if need_grad or dropping:
             agg, pos = _new((B * N, hd), x), _new((B * N, hd), x)
             lse, q = _new((B * N, H), x), _new((B * N, H), x)
-        _lib.call("gatmi_dense_attn_fwd", B, N, H, dp, ptr(Wh), ptr(f1), ptr(f2), ptr(bias_mat), ptr(biasp), ptr(res),
-                  _ACT[cfg.activation], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
-                  ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), st)
+        lists = _use_mask_lists(cfg, bias_mat)
+        present = None
+        if lists:
+            if agg is not None:      # visited-entry bits for the backward pass
+                present = torch.empty((B * N, _lib.lib.gatmi_dense_mask_words(N)), dtype=torch.int32, device=x.device)
+            _lib.call("gatmi_dense_attn_fwd_masked", B, N, H, dp, ptr(Wh), ptr(f1), ptr(f2), ptr(bias_mat), ptr(biasp), ptr(res),
+                      _ACT[cfg.activation], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
+                      ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(present), st)
+        else:
+            _lib.call("gatmi_dense_attn_fwd", B, N, H, dp, ptr(Wh), ptr(f1), ptr(f2), ptr(bias_mat), ptr(biasp), ptr(res),
+                      _ACT[cfg.activation], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
+                      ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), st)
         if need_grad:
-            ctx.cfg, ctx.dims = cfg, (B, N)
+            ctx.cfg, ctx.dims, ctx.present = cfg, (B, N), present
             ctx.has_bias, ctx.has_res = bias is not None, W_res is not None
             ctx.save_for_backward(x2, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q, bias_mat)
         o = out.reshape(B, N, H, dp)
@@ -261,8 +311,13 @@ class DenseGATLayerFn(torch.autograd.Function):
                   _ACT[cfg.activation], _lib.REDUCE_CONCAT, cfg.slope, ptr(g), None, ptr(stats), ptr(df1), ptr(dbias), ptr(ws), st)
         dWh = _new((n, hd), x2)
         df2 = _new((n, H), x2)
-        _lib.call("gatmi_dense_attn_bwd", B, N, H, dp, ptr(g), ptr(stats), ptr(Wh), ptr(f2), ptr(bias_mat),
-                  ptr(df1), ptr(a1p), ptr(a2p), cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dWh), ptr(df2), st)
+        if ctx.present is not None:
+            _lib.call("gatmi_dense_attn_bwd_masked", B, N, H, dp, ptr(g), ptr(stats), ptr(Wh), ptr(f2), ptr(bias_mat),
+                      ptr(df1), ptr(a1p), ptr(a2p), ptr(ctx.present), cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
+                      ptr(dWh), ptr(df2), st)
+        else:
+            _lib.call("gatmi_dense_attn_bwd", B, N, H, dp, ptr(g), ptr(stats), ptr(Wh), ptr(f2), ptr(bias_mat),
+                      ptr(df1), ptr(a1p), ptr(a2p), cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dWh), ptr(df2), st)
         dx, dW, da1, da2, db1, db2, dWr = _project_backward(x2, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
         if dx is not None:
             dx = dx.reshape(B, N, -1)
@@ -272,12 +327,14 @@ class DenseGATLayerFn(torch.autograd.Function):
 
 
 def make_cfg(H, D, activation="elu", reduce="concat", coef_drop=0.0, in_drop=0.0, training=False, seed=None,
-             slope=LEAKY_SLOPE, storage="f32"):
+             slope=LEAKY_SLOPE, storage="f32", mask_path="auto"):
     """Static description of one layer call.  coef_drop / in_drop are the reference's dropout
     rates (utils/layers.py:20,22); they act only when training is true, and rate 0 is an exact
     identity (no mask is drawn).  storage="bf16" keeps the two gathered tables of the CSR path (Wh
     rows in the forward sweep, g rows in the backward sweep) in bf16 — half the gather traffic,
-    fp32 arithmetic, results within the 2e-2 class instead of 1e-5."""
+    fp32 arithmetic, results within the 2e-2 class instead of 1e-5.  mask_path (dense [B,N,N] masks
+    only): "auto" picks the compacted-list kernels for sparse masks and the matrix-core kernels for
+    dense ones; "lists" / "dense" force one of them (same results)."""
     if activation not in _ACT:
         raise ValueError("activation must be 'elu' or 'identity', got %r" % (activation,))
     if not supported_shape(H, D):
@@ -296,6 +353,9 @@ def make_cfg(H, D, activation="elu", reduce="concat", coef_drop=0.0, in_drop=0.0
     if storage == "bf16" and (c.coef_keep < 1.0 or c.feat_keep < 1.0):
         raise ValueError("bf16 storage of the gathered tables is built without in-kernel dropout")
     c.storage = storage
+    if mask_path not in ("auto", "lists", "dense"):
+        raise ValueError("mask_path must be 'auto', 'lists' or 'dense'")
+    c.mask_path = mask_path
     return c
 
 

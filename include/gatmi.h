@@ -242,6 +242,31 @@ int gatmi_dense_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t dp,
                          float slope, float coef_keep, float feat_keep, uint64_t seed,
                          float *dWh, float *df2, void *stream);
 
+/* The same two operations for SPARSE masks (same results): instead of sweeping all N x N entries
+ * through the matrix cores, the forward kernel reads the mask rows once, compacts the column indices
+ * that can contribute into LDS and visits only those.  It visits (i, j) iff
+ * bias_mat[b,i,j] > max_j' bias_mat[b,i,j'] - 1e6; every skipped entry has a softmax coefficient of
+ * exactly 0 in fp32 as long as the logits stay below 4e5 in magnitude, so adj_to_bias masks
+ * (0 / -1e9, utils/process.py:25), soft biases and rows that are masked everywhere (all entries
+ * kept) give what the dense kernels give.  `present` [B*N, gatmi_dense_mask_words(N)] uint32 (may be
+ * NULL when agg..q are NULL) receives one bit per visited entry plus a flag word per row; the
+ * backward kernel walks those bits instead of reading the fp32 mask again (it fetches bias values
+ * only in rows whose visited entries are not all zero).  Faster than the dense kernels when about a
+ * third or fewer of the entries of a row contribute; H*dp >= 32, N <= 32767. */
+size_t gatmi_dense_mask_words(int32_t N);
+int gatmi_dense_attn_fwd_masked(int64_t B, int32_t N, int32_t H, int32_t dp,
+                                const float *Wh, const float *f1, const float *f2, const float *bias_mat,
+                                const float *bias, const float *resid, int32_t activation, float slope,
+                                float coef_keep, float feat_keep, uint64_t seed,
+                                float *out, float *agg, float *pos, float *lse, float *q,
+                                uint32_t *present, void *stream);
+int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int32_t dp,
+                                const float *g, const float *stats, const float *Wh, const float *f2,
+                                const float *bias_mat, const float *df1, const float *a1, const float *a2,
+                                const uint32_t *present,
+                                float slope, float coef_keep, float feat_keep, uint64_t seed,
+                                float *dWh, float *df2, void *stream);
+
 /* Brain-network variant of the attention step: the inner loop body of attn_e2v_BNF_V2
  * (utils/layers.py:174-179) with the coefficients of attn_v2e_BNF_V2 (:229-237), for H heads that
  * share X and the weighted adjacency A but own their projection (f1, f2) and the scalars m1, m2

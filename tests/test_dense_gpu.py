@@ -31,12 +31,20 @@ CASES = [
     (4, 19, 5, 2, 4, "elu", True),
     (1, 1000, 10, 8, 8, "elu", False),      # too large for the LDS-resident kernels: chunked path
     (1, 530, 8, 1, 64, "identity", False),  # same for a single wide head
+    (3, 300, 10, 4, 8, "elu", True),        # 32-float rows: 8 lanes per row in the list kernels, two list passes
+    (1, 70, 8, 4, 64, "elu", False),        # 256-float rows: one row per wave
 ]
 
 
+@pytest.mark.parametrize("path", ["dense", "lists"])
 @pytest.mark.parametrize("B,N,F,H,D,activation,soft", CASES)
-def test_dense_layer_forward_and_gradients(B, N, F, H, D, activation, soft):
+def test_dense_layer_forward_and_gradients(B, N, F, H, D, activation, soft, path):
+    """path: the matrix-core kernels ("dense") or the compacted-list kernels for sparse masks ("lists")."""
     from gat_amd import ops
+    if path == "lists" and H * ops.padded_width(D) < 32:
+        pytest.skip("the list kernels take rows of at least 32 floats")
+    if path == "dense" and H * ops.padded_width(D) > 64:
+        path = "auto"          # rows wider than the matrix-core kernels take: auto routes them to the list kernels
     dev = torch.device("cuda:0")
     p = layer_params(F, H, D, seed=N, res=(N == 50))
     rng = np.random.default_rng(N + 1)
@@ -44,7 +52,7 @@ def test_dense_layer_forward_and_gradients(B, N, F, H, D, activation, soft):
     bm = _masks(B, N, 0.15, N + 2, soft)
     tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
     xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
-    cfg = ops.make_cfg(H, D, activation=activation)
+    cfg = ops.make_cfg(H, D, activation=activation, mask_path=path)
     out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"],
                               torch.tensor(bm, dtype=torch.float32, device=dev), cfg, tp.get("W_res"), tp.get("b_res"))
     act = ref_numpy.elu if activation == "elu" else ref_numpy.identity
@@ -95,7 +103,37 @@ def test_dense_equals_sparse_on_the_same_graph():
     assert_close(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-6, atol_scale=1e-6, what="dense vs sparse")
 
 
-def test_padded_batch_with_per_graph_sizes():
+def test_rows_masked_everywhere_and_automatic_choice():
+    """A row whose mask is -1e9 in every column attends uniformly in fp32 (the -1e9 swallows the
+    logits): both kernel families give that.  'auto' measures the density once per mask tensor."""
+    from gat_amd import ops
+    dev = torch.device("cuda:0")
+    B, N, F, H, D = 2, 40, 6, 8, 8
+    rng = np.random.default_rng(0)
+    bm = _masks(B, N, 0.1, 3)
+    bm[0, 5, :] = -1e9
+    bm[1, 0, :] = -1e9
+    p = layer_params(F, H, D, seed=1)
+    tp = {k: torch.tensor(v, dtype=torch.float32, device=dev) for k, v in p.items()}
+    x = torch.tensor(rng.normal(0, 1, (B, N, F)), dtype=torch.float32, device=dev)
+    bt = torch.tensor(bm, dtype=torch.float32, device=dev)
+    outs = {}
+    for path in ("dense", "lists", "auto"):
+        outs[path] = ops.dense_gat_layer(x, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], bt,
+                                         ops.make_cfg(H, D, "elu", mask_path=path)).cpu().numpy()
+    assert_close(outs["lists"], outs["dense"], rtol=2e-6, atol_scale=1e-6, what="lists vs dense")
+    assert np.array_equal(outs["auto"], outs["lists"])          # density 0.1: auto takes the list kernels
+    wh = (x.cpu().numpy().astype(np.float64) @ p["W"].reshape(F, H * D))
+    uniform = ref_numpy.elu(wh[0].mean(0) + p["bias"].reshape(-1))
+    assert_close(outs["lists"][0, 5], uniform, rtol=1e-5, atol_scale=1e-5, what="uniform row")
+    assert ops._mask_density(bt) < 0.2
+    dense_mask = torch.zeros(B, N, N, device=dev)
+    assert ops._mask_density(dense_mask) == 1.0
+    assert not ops._use_mask_lists(ops.make_cfg(H, D), dense_mask)
+
+
+@pytest.mark.parametrize("path", ["dense", "lists"])
+def test_padded_batch_with_per_graph_sizes(path):
     """Graphs of different sizes padded to one [G,N,N] batch (process_ppi.py:183-215) and masked by
     adj_to_bias(adj, sizes): the binarised block covers each graph's own nodes, padded nodes keep
     the raw (I+I) diagonal, i.e. a +1e9 bias, and therefore attend to themselves only.  Real
@@ -117,7 +155,7 @@ def test_padded_batch_with_per_graph_sizes():
     p = layer_params(F, H, D, seed=5)
     tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
     xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
-    cfg = ops.make_cfg(H, D, activation="elu")
+    cfg = ops.make_cfg(H, D, activation="elu", mask_path=path)
     out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"],
                               torch.tensor(bm, dtype=torch.float32, device=dev), cfg)
     ref = ref_numpy.gat_layer_dense(x, p, bm, ref_numpy.elu, "concat")

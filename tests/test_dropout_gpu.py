@@ -89,11 +89,15 @@ def test_rate_zero_and_eval_are_exact_identities():
     assert not torch.equal(dropped, run(ops.make_cfg(H, D, "elu", coef_drop=0.6, in_drop=0.6, training=True, seed=6)))
 
 
+@pytest.mark.parametrize("path", ["dense", "lists"])
 @pytest.mark.parametrize("B,N,H,D,coef_drop,in_drop", [(2, 60, 8, 8, 0.6, 0.6), (1, 700, 8, 8, 0.5, 0.3), (3, 33, 1, 7, 0.4, 0.0)])
-def test_dense_layer_masks_replay(B, N, H, D, coef_drop, in_drop):
-    """Same check for the dense kernels (both the LDS-resident and the chunked variants): masks are
+def test_dense_layer_masks_replay(B, N, H, D, coef_drop, in_drop, path):
+    """Same check for the dense kernels (the LDS-resident and the chunked matrix-core variants, and
+    the compacted-list kernels, which draw the very same masks): masks are
     keyed on (graph, i, j, head) and (graph, j, padded column)."""
     from gat_amd import ops
+    if path == "lists" and H * ops.padded_width(D) < 32:
+        pytest.skip("the list kernels take rows of at least 32 floats")
     dev = torch.device("cuda:0")
     F = 12
     dp = ops.padded_width(D)
@@ -105,7 +109,7 @@ def test_dense_layer_masks_replay(B, N, H, D, coef_drop, in_drop):
     seed = 987654321
     tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
     xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
-    cfg = ops.make_cfg(H, D, "elu", "concat", coef_drop=coef_drop, in_drop=in_drop, training=True, seed=seed)
+    cfg = ops.make_cfg(H, D, "elu", "concat", coef_drop=coef_drop, in_drop=in_drop, training=True, seed=seed, mask_path=path)
     out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"],
                               torch.tensor(bm, dtype=torch.float32, device=dev), cfg)
     dout = rng.normal(0, 1, tuple(out.shape))
