@@ -81,7 +81,7 @@ __device__ __forceinline__ void load_ids(const uint16_t *lp, int (&ids)[kBatch])
 // gathers need one 32-bit multiply-add per address (row ids of one graph are below 2^15).
 template <int G, int LPH, bool SAVE, bool DROP>
 __device__ __forceinline__ void masked_fwd_batch(MRowState &st, const MaskedFwdArgs &a, const uint16_t *lp, int nvalid,
-                                                 int64_t b, int i, const float *bm, const float *whb, const float *f2b,
+                                                 int64_t b, int i, const float *bm, bool soft, const float *whb, const float *f2b,
                                                  float f1v, int sub, int head) {
     constexpr int H = G / LPH;
     constexpr int HD = 4 * G;
@@ -96,7 +96,7 @@ __device__ __forceinline__ void masked_fwd_batch(MRowState &st, const MaskedFwdA
         if (t >= nvalid) j[t] = j[0];
         z[t] = f1v + f2b[(uint32_t)j[t] * H];
         v[t] = *reinterpret_cast<const float4 *>(whb + (uint32_t)j[t] * HD);
-        e[t] = bm[(uint32_t)j[t]];
+        e[t] = soft ? bm[(uint32_t)j[t]] : 0.f;          // rows whose visited entries are all 0 need no bias values
     }
     float mn = st.m;
 #pragma unroll
@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256, GATMI_MASK_MINBLOCKS) void dense_masked_fwd_ke
             }
         }
         int mycnt = 0;
+        bool mysoft = false;
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             float mx = -INFINITY;
@@ -227,7 +228,10 @@ __global__ __launch_bounds__(256, GATMI_MASK_MINBLOCKS) void dense_masked_fwd_ke
             }
             const uint64_t nzb = __ballot(nonzero);
             if (prow && lane == 0) prow[W - 1] = nzb != 0 ? 1u : 0u;
-            if (rr == grp) mycnt = cnt;
+            if (rr == grp) {
+                mycnt = cnt;
+                mysoft = nzb != 0;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256, GATMI_MASK_MINBLOCKS) void dense_masked_fwd_ke
         if (row_ok) {
             const uint16_t *lp = lists[wave][grp];
             for (int k = 0; k < mycnt; k += kBatch)
-                masked_fwd_batch<G, LPH, SAVE, DROP>(st, a, lp + k, min(kBatch, mycnt - k), b, i, bm_own, whb, f2b, f1v, sub, head);
+                masked_fwd_batch<G, LPH, SAVE, DROP>(st, a, lp + k, min(kBatch, mycnt - k), b, i, bm_own, mysoft, whb, f2b, f1v, sub, head);
         }
     } else {
         // General sizes: row maxima first (one row of the wave at a time with all 64 lanes), then the
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(256, GATMI_MASK_MINBLOCKS) void dense_masked_fwd_ke
         for (int seg0 = 0; seg0 < N; seg0 += LC) {
             const int seg_end = min(N, seg0 + LC);
             int mycnt = 0;
+            bool mysoft = false;
             for (int rr = 0; rr < RPW; ++rr) {               // compact the contributing columns of row row0 + rr
                 const float *bm = bmat + (int64_t)min(row0 + rr, N - 1) * N;
                 const float cut = __shfl(bmax, rr * G, 64) - kMaskCutoffFwd;
@@ -277,7 +282,10 @@ __global__ __launch_bounds__(256, GATMI_MASK_MINBLOCKS) void dense_masked_fwd_ke
                     const uint32_t f = nzb != 0 ? 1u : 0u;
                     prow[W - 1] = seg0 == 0 ? f : (prow[W - 1] | f);
                 }
-                if (rr == grp) mycnt = cnt;
+                if (rr == grp) {
+                    mycnt = cnt;
+                    mysoft = nzb != 0;
+                }
             }
             // the lists are written and read by this wave only; its lanes run in lockstep
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(256, GATMI_MASK_MINBLOCKS) void dense_masked_fwd_ke
             if (row_ok) {
                 const uint16_t *lp = lists[wave][grp];
                 for (int k = 0; k < mycnt; k += kBatch)
-                    masked_fwd_batch<G, LPH, SAVE, DROP>(st, a, lp + k, min(kBatch, mycnt - k), b, i, bm_own, whb, f2b, f1v, sub, head);
+                    masked_fwd_batch<G, LPH, SAVE, DROP>(st, a, lp + k, min(kBatch, mycnt - k), b, i, bm_own, mysoft, whb, f2b, f1v, sub, head);
             }
             __builtin_amdgcn_wave_barrier();                 // all reads done before the next pass overwrites the lists
         }
