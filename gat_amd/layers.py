@@ -271,3 +271,53 @@ def InnerProductDecoder(seq, activation="sigmoid", dropout=0.0):
     graph, as the reference returns it (callers reshape to [-1,N,N], models/gat.py:206).
     activation: "sigmoid" (the reference's default, tf.nn.sigmoid) or "identity"."""
     return ops.inner_product_decoder(seq, activation, dropout).reshape(-1)
+
+
+class AttnE2VBNFV2(nn.Module):
+    """`attn_e2v_BNF_V2` (utils/layers.py:158-227): `reps` (5 in the reference, :171) rounds of
+    n_heads brain-network attention steps (BNFAttention: the libgatmi kernels), each head followed
+    by conv1d(agg, out_sz, 1, activation) (:180), the heads concatenated and merged by another
+    conv1d (:182-183), with the reference's residual rule (:185-191: a projection when widths
+    differ, a plain sum otherwise); the five round outputs are concatenated (:221), passed through two
+    conv1d layers (:223-224) and l2-normalised over the node axis (:225).  Returns (out [B,N,out_sz],
+    aggall [B,N,reps*out_sz]).  The width-1 convolutions are ordinary dense layers (torch)."""
+
+    def __init__(self, f_in, out_sz, n_heads, activation="relu", residual=False, reps=5, feat_dim=64, device=None):
+        super().__init__()
+        if activation not in ("relu", "elu", "identity"):
+            raise ValueError("activation must be 'relu', 'elu' or 'identity'")
+        self.activation, self.residual, self.reps, self.n_heads, self.out_sz = activation, bool(residual), reps, n_heads, out_sz
+        kw = {"device": device, "dtype": torch.float32}
+        self.att, self.head_w, self.head_b, self.merge, self.res = nn.ModuleList(), nn.ParameterList(), nn.ParameterList(), nn.ModuleList(), nn.ModuleList()
+        for rep in range(reps):
+            f = f_in if rep == 0 else out_sz
+            self.att.append(BNFAttention(f, n_heads, feat_dim, device=device))
+            w = torch.empty(n_heads, f, out_sz, **kw)
+            lim = math.sqrt(6.0 / (f + out_sz))
+            self.head_w.append(nn.Parameter(w.uniform_(-lim, lim)))
+            self.head_b.append(nn.Parameter(torch.zeros(n_heads, out_sz, **kw)))
+            self.merge.append(nn.Linear(n_heads * out_sz, out_sz, **kw))
+            self.res.append(nn.Linear(f, out_sz, **kw) if (self.residual and f != out_sz) else nn.Identity())
+        self.out1 = nn.Linear(reps * out_sz, out_sz, **kw)
+        self.out2 = nn.Linear(out_sz, out_sz, **kw)
+
+    def _act(self, x):
+        if self.activation == "relu":
+            return torch.relu(x)
+        return torch.nn.functional.elu(x) if self.activation == "elu" else x
+
+    def forward(self, seq, net_mat):
+        seq_out, outs = seq, []
+        for rep in range(self.reps):
+            agg = self.att[rep](seq_out, net_mat)                                        # [B,N,H,F]   layers.py:174-179
+            heads = self._act(torch.einsum("bnhf,hfo->bnho", agg, self.head_w[rep]) + self.head_b[rep])   # :180
+            merged = self._act(self.merge[rep](heads.flatten(2)))                       # :182-183
+            if self.residual:
+                seq_out = merged + self.res[rep](seq_out)                               # :185-189
+            else:
+                seq_out = merged
+            outs.append(seq_out)
+        aggall = torch.cat(outs, dim=-1)
+        out = self._act(self.out2(self._act(self.out1(aggall))))
+        out = out / torch.sqrt(torch.clamp((out * out).sum(dim=-2, keepdim=True), min=1e-12))   # tf.nn.l2_normalize(axis=-2)
+        return out, aggall

@@ -103,3 +103,48 @@ class SpGAT(BaseGAttN):
             return layers.sp_attn_heads(seq, out_sz, g, act, nb_nodes, nh, reduce, in_drop, coef_drop, res, train)
         return _compose(head_fn, inputs, nb_classes, _is_training(training, attn_drop, ffd_drop), attn_drop, ffd_drop,
                         graph, hid_units, n_heads, activation, residual)
+
+
+class GAT_AE_BNF_V2(torch.nn.Module):
+    """models/gat.py:188-243 — the brain-network auto-encoder that BNF_AE.py:28 selects.  Two
+    `reconstruction` branches (:194-216), each: batch-normalised connectivity (:201) ->
+    attn_e2v_BNF_V2 with residual=True (:202) -> InnerProductDecoder (:204-206) and, after dropout
+    with keep 0.7 in training (:209-210), conv1d(.,64,1) (:212); the two node embeddings are
+    concatenated (:219), mapped to nb_CAM channels (:231), averaged over nodes (:233) and classified
+    (:234); `cam` applies the classifier's kernel per node (:236-239).  TensorFlow builds variables
+    per call; here they are created once for a fixed (f_in, nb_nodes).  The attention steps and the
+    decoder run on the libgatmi kernels, the width-1 convolutions and the batch norm on torch."""
+
+    def __init__(self, f_in, nb_nodes, nb_classes, nb_CAM, hid_units, n_heads, device=None):
+        super().__init__()
+        from .layers import AttnE2VBNFV2
+        kw = {"device": device, "dtype": torch.float32}
+        self.nb_nodes, self.nb_classes = nb_nodes, nb_classes
+        # tf.contrib.layers.batch_norm defaults: statistics over all but the last axis, center only
+        # (scale=False), epsilon 1e-3, decay 0.999, is_training=True
+        self.bn = torch.nn.ModuleList([torch.nn.BatchNorm1d(nb_nodes, eps=1e-3, momentum=1e-3, affine=False, **kw) for _ in range(2)])
+        self.bn_beta = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(nb_nodes, **kw)) for _ in range(2)])
+        self.e2v = torch.nn.ModuleList([AttnE2VBNFV2(f_in, hid_units[0], n_heads[0], "relu", residual=True, device=device) for _ in range(2)])
+        self.node_fc1 = torch.nn.ModuleList([torch.nn.Linear(hid_units[0], 64, **kw) for _ in range(2)])
+        self.node_fc2 = torch.nn.Linear(128, nb_CAM, **kw)
+        self.dense_out = torch.nn.Linear(nb_CAM, nb_classes, **kw)
+
+    def _reconstruction(self, k, inputs, net_mat, training):
+        B, N, _ = net_mat.shape
+        nm = self.bn[k](net_mat.reshape(B * N, N)).reshape(B, N, N) + self.bn_beta[k]
+        emb, _ = self.e2v[k](inputs, nm)
+        graph = layers.InnerProductDecoder(emb).reshape(-1, N, N)
+        if training:
+            emb = torch.nn.functional.dropout(emb, 0.3, True)
+        return torch.relu(self.node_fc1[k](emb)), graph
+
+    def forward(self, inputs, net_mat, training=False):
+        """inputs [B,N,F], net_mat [B,N,N] -> (digits [B,C], reconstruct_fmri [B,N,N],
+        reconstruct_DTI [B,N,N], softmax(digits), cam [B,N,C]); the reference's `inference`
+        returns the same five values."""
+        fc_a, rec_a = self._reconstruction(0, inputs, net_mat, training)
+        fc_b, rec_b = self._reconstruction(1, inputs, net_mat, training)
+        node_fc2 = torch.relu(self.node_fc2(torch.cat([fc_a, fc_b], dim=-1)))
+        digits = self.dense_out(node_fc2.mean(dim=-2))
+        cam = node_fc2 @ self.dense_out.weight.t()
+        return digits, rec_a, rec_b, torch.softmax(digits, dim=-1), cam

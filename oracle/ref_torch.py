@@ -133,3 +133,26 @@ def inner_product_decoder(z, activation="sigmoid", keep=1.0, mask=None):
     x = inputs @ inputs.transpose(1, 2)
     x = x.reshape(-1)
     return torch.sigmoid(x) if activation == "sigmoid" else x
+
+
+def attn_e2v_bnf_v2(x, net_mat, rounds, out1, out2, activation="relu", residual=False):
+    """attn_e2v_BNF_V2 (utils/layers.py:158-227) with explicit weights.  rounds: one dict per
+    repetition (:171) with the attention parameters of bnf_v2e_aggregate plus head_w [H,F,out],
+    head_b [H,out] (:180), merge_w [H*out,out], merge_b (:183), and res_w / res_b when the residual
+    needs a projection (:187).  out1 / out2: (weight [in,out], bias) of the closing conv1d layers
+    (:223-224).  Returns (out, aggall)."""
+    act = {"relu": torch.relu, "elu": F.elu, "identity": lambda t: t}[activation]
+    seq_out, outs = x, []
+    for r in rounds:
+        agg = bnf_v2e_aggregate(seq_out, net_mat, r)                                   # [B,N,H,F]
+        heads = act(torch.einsum("bnhf,hfo->bnho", agg, r["head_w"]) + r["head_b"])
+        merged = act(heads.flatten(2) @ r["merge_w"] + r["merge_b"])
+        if residual:
+            seq_out = merged + (seq_out @ r["res_w"] + r["res_b"] if "res_w" in r else seq_out)
+        else:
+            seq_out = merged
+        outs.append(seq_out)
+    aggall = torch.cat(outs, dim=-1)
+    out = act(act(aggall @ out1[0] + out1[1]) @ out2[0] + out2[1])
+    out = out / torch.sqrt(torch.clamp((out * out).sum(dim=-2, keepdim=True), min=1e-12))   # l2_normalize(axis=-2), :225
+    return out, aggall

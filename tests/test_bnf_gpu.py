@@ -42,3 +42,67 @@ def test_bnf_aggregate_forward_and_gradients(B, N, F, H, Dz):
     assert_close(At.grad.cpu().numpy(), rA.grad.numpy(), atol_scale=5e-6, what="bnf dA")
     for k in ("W", "a1", "a2", "m1", "m2"):
         assert_close(getattr(mod, k).grad.cpu().numpy(), rp[k].grad.numpy(), rtol=2e-5, atol_scale=1e-5, what="bnf d" + k)
+
+
+@pytest.mark.parametrize("F,out_sz,heads,residual", [(1, 16, 2, True), (8, 8, 3, False)])
+def test_attn_e2v_bnf_v2_composition(F, out_sz, heads, residual):
+    """attn_e2v_BNF_V2 (utils/layers.py:158-227): five rounds of attention heads on the kernels with
+    the reference's dense layers around them, against the float64 restatement with the same weights."""
+    from gat_amd.layers import AttnE2VBNFV2
+    dev = torch.device("cuda:0")
+    B, N = 3, 50
+    rng = np.random.default_rng(F)
+    x = rng.normal(0, 1, (B, N, F))
+    A = rng.random((B, N, N)) * (rng.random((B, N, N)) < 0.2)
+    A = (A + A.transpose(0, 2, 1)) / 2
+    torch.manual_seed(0)
+    mod = AttnE2VBNFV2(F, out_sz, heads, "relu", residual, reps=5, feat_dim=16, device=dev)
+    with torch.no_grad():
+        for att in mod.att:                      # non-trivial logit biases and scalars
+            att.b1.normal_(0, 0.1); att.b2.normal_(0, 0.1); att.m1.add_(torch.randn_like(att.m1) * 0.1); att.m2.add_(torch.randn_like(att.m2) * 0.1)
+    xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
+    At = torch.tensor(A, dtype=torch.float32, device=dev)
+    out, aggall = mod(xt, At)
+    assert tuple(out.shape) == (B, N, out_sz) and tuple(aggall.shape) == (B, N, 5 * out_sz)
+    d = lambda t: t.detach().cpu().double().requires_grad_(True)
+    rounds = []
+    for rep in range(5):
+        att = mod.att[rep]
+        r = {k: d(getattr(att, k)) for k in ("W", "a1", "a2", "b1", "b2", "m1", "m2")}
+        r.update(head_w=d(mod.head_w[rep]), head_b=d(mod.head_b[rep]), merge_w=d(mod.merge[rep].weight.t()), merge_b=d(mod.merge[rep].bias))
+        if isinstance(mod.res[rep], torch.nn.Linear):
+            r.update(res_w=d(mod.res[rep].weight.t()), res_b=d(mod.res[rep].bias))
+        rounds.append(r)
+    rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    rout, ragg = ref_torch.attn_e2v_bnf_v2(rx, torch.tensor(A), rounds, (d(mod.out1.weight.t()), d(mod.out1.bias)),
+                                           (d(mod.out2.weight.t()), d(mod.out2.bias)), "relu", residual)
+    assert_close(aggall.detach().cpu().numpy(), ragg.detach().numpy(), rtol=2e-5, atol_scale=1e-5, what="e2v aggall")
+    assert_close(out.detach().cpu().numpy(), rout.detach().numpy(), rtol=2e-5, atol_scale=1e-5, what="e2v out")
+    g = rng.normal(0, 1, tuple(aggall.shape))
+    aggall.backward(torch.tensor(g, dtype=torch.float32, device=dev))
+    ragg.backward(torch.tensor(g))
+    assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), rtol=1e-4, atol_scale=5e-5, what="e2v dX")
+    assert_close(mod.att[0].W.grad.cpu().numpy(), rounds[0]["W"].grad.numpy(), rtol=1e-4, atol_scale=5e-5, what="e2v dW(round 0)")
+    assert_close(mod.att[4].m1.grad.cpu().numpy(), rounds[4]["m1"].grad.numpy(), rtol=1e-4, atol_scale=5e-5, what="e2v dm1(round 4)")
+
+
+def test_gat_ae_bnf_v2_model_runs_on_the_kernels():
+    """models/gat.py:188-243 at a reduced size: output shapes, reconstructions in (0,1) and
+    symmetric (sigmoid of a Gram matrix), class-activation map consistent with the logits
+    (mean over nodes of cam + bias = digits), gradients reach every parameter."""
+    from gat_amd.models import GAT_AE_BNF_V2
+    dev = torch.device("cuda:0")
+    B, N, F, C = 4, 90, 1, 2
+    torch.manual_seed(1)
+    net = torch.rand(B, N, N, device=dev) * (torch.rand(B, N, N, device=dev) < 0.3)
+    net = (net + net.transpose(1, 2)) / 2
+    x = torch.randn(B, N, F, device=dev)
+    model = GAT_AE_BNF_V2(F, N, C, nb_CAM=32, hid_units=[16, 8, 8], n_heads=[2, 2, 2], device=dev)
+    digits, rec_a, rec_b, prob, cam = model(x, net, training=True)
+    assert tuple(digits.shape) == (B, C) and tuple(rec_a.shape) == (B, N, N) == tuple(rec_b.shape) and tuple(cam.shape) == (B, N, C)
+    assert (rec_a > 0).all() and (rec_a < 1).all() and torch.allclose(rec_a, rec_a.transpose(1, 2), atol=1e-6)
+    assert torch.allclose(prob.sum(-1), torch.ones(B, device=dev), atol=1e-5)
+    assert torch.allclose(cam.mean(1) + model.dense_out.bias, digits, atol=1e-4)
+    (digits.sum() + rec_a.mean() + rec_b.mean()).backward()
+    missing = [n for n, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not missing, missing
