@@ -59,11 +59,24 @@ __device__ __forceinline__ float coef_drop_scale(uint64_t seed, int64_t b, int N
 }
 
 // float4 arithmetic of the row kernels (one float4 of a feature row per lane)
+// Written on two-element vectors so that the compiler can use the packed fp32 instructions of
+// CDNA3/4 (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32: two lanes' worth of fp32 per issue slot).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 y) {
-    return make_float4(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z), fmaf(a, x.w, y.w));
+    const f32x2_t s = {a, a};
+    const f32x2_t lo = __builtin_elementwise_fma(s, (f32x2_t){x.x, x.y}, (f32x2_t){y.x, y.y});
+    const f32x2_t hi = __builtin_elementwise_fma(s, (f32x2_t){x.z, x.w}, (f32x2_t){y.z, y.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
-__device__ __forceinline__ float4 f4_scale(float a, float4 x) { return make_float4(a * x.x, a * x.y, a * x.z, a * x.w); }
-__device__ __forceinline__ float4 f4_add(float4 x, float4 y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); }
+__device__ __forceinline__ float4 f4_scale(float a, float4 x) {
+    const f32x2_t s = {a, a};
+    const f32x2_t lo = s * (f32x2_t){x.x, x.y}, hi = s * (f32x2_t){x.z, x.w};
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ __forceinline__ float4 f4_add(float4 x, float4 y) {
+    const f32x2_t lo = (f32x2_t){x.x, x.y} + (f32x2_t){y.x, y.y}, hi = (f32x2_t){x.z, x.w} + (f32x2_t){y.z, y.w};
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
 __device__ __forceinline__ float dot4(float4 x, float4 y) { return fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, x.w * y.w))); }
 
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
