@@ -213,7 +213,9 @@ _density_cache = {}
 def _mask_density(bias_mat):
     """Fraction of mask entries that can contribute (within 1e6 of their row's maximum), estimated on
     the first graphs of the batch and remembered per tensor version.  None while a HIP graph is being
-    captured and nothing is remembered (the estimate needs a device-to-host copy)."""
+    captured and nothing is remembered (the estimate needs a device-to-host copy).  The memo is keyed
+    on address, shape and version counter; a different mask that reuses a freed tensor's address can
+    inherit its estimate, which can only cost speed: both kernel families give the same results."""
     key = (bias_mat.data_ptr(), tuple(bias_mat.shape), bias_mat._version)
     d = _density_cache.get(key)
     if d is None:
