@@ -27,10 +27,20 @@ def auto_chunk(nnz):
     return c
 
 
-def _work_items(ptr_host, chunk):
-    """gatmi_work_items on a host int64 pointer array -> (items [n_items,4] int32, split [n_split,4] int32, n_slots)."""
+def _work_items(ptr_host, chunk, order="length"):
+    """gatmi_work_items on a host int64 pointer array -> (items [n_items,4] int32, split [n_split,4] int32, n_slots).
+    order="rows" keeps the rows in their own order instead of longest first (possible when no row is
+    longer than the chunk): neighbouring row groups then read neighbouring sources, which is what
+    a batch of small graphs wants; a power-law graph wants the length sort."""
     n = len(ptr_host) - 1
     ptr_host = np.ascontiguousarray(ptr_host, dtype=np.int64)
+    if order == "rows" and n > 0 and int(np.diff(ptr_host).max()) <= chunk:
+        items = np.empty((n, 4), dtype=np.int32)
+        items[:, 0] = np.arange(n, dtype=np.int32)
+        items[:, 1] = ptr_host[:-1]
+        items[:, 2] = np.diff(ptr_host)
+        items[:, 3] = -1
+        return items, np.empty((0, 4), dtype=np.int32), 0
     n_items, n_split, n_slots = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
     _lib.call("gatmi_work_items_count", n, _lib.ptr(ptr_host), chunk,
               ctypes.byref(n_items), ctypes.byref(n_split), ctypes.byref(n_slots))
@@ -75,7 +85,7 @@ class CSRGraph:
     row partitioning n_src = owned + halo rows.
     """
 
-    def __init__(self, n_dst, n_src, rowptr, col, colptr, rowidx, perm, device, chunk=DEFAULT_CHUNK):
+    def __init__(self, n_dst, n_src, rowptr, col, colptr, rowidx, perm, device, chunk=DEFAULT_CHUNK, order="length"):
         self.n_dst, self.n_src = int(n_dst), int(n_src)
         self.device = torch.device(device)
         self.rowptr_host = np.ascontiguousarray(rowptr, dtype=np.int64)
@@ -86,9 +96,9 @@ class CSRGraph:
         self.col = to(col, torch.int32)
         self.rowidx = to(rowidx, torch.int32)
         self.perm = to(perm, torch.int32)
-        it, sp, self.n_slots_csr = _work_items(self.rowptr_host, self.chunk)
+        it, sp, self.n_slots_csr = _work_items(self.rowptr_host, self.chunk, order)
         self.items_csr, self.split_csr = to(it, torch.int32), to(sp, torch.int32)
-        it, sp, self.n_slots_csc = _work_items(self.colptr_host, self.chunk)
+        it, sp, self.n_slots_csc = _work_items(self.colptr_host, self.chunk, order)
         self.items_csc, self.split_csc = to(it, torch.int32), to(sp, torch.int32)
 
     # ---- constructors -------------------------------------------------------------------------
@@ -116,7 +126,7 @@ class CSRGraph:
         return cls(n_dst, n_src, rowptr, col, colptr, rowidx, perm, device, chunk)
 
     @classmethod
-    def from_device_coo(cls, dst, src, n_dst, n_src, chunk=DEFAULT_CHUNK):
+    def from_device_coo(cls, dst, src, n_dst, n_src, chunk=DEFAULT_CHUNK, item_order="length"):
         """Large graphs already on the GPU: dst/src int64 device tensors with DISTINCT (dst, src)
         pairs.  Sorting runs on the device; only the two pointer arrays visit the host (for the
         work-item builder).  Produces the same arrays as the host path."""
@@ -134,7 +144,28 @@ class CSRGraph:
         colptr = torch.zeros(n_src + 1, dtype=torch.int64, device=dev)
         colptr[1:] = torch.cumsum(torch.bincount(col.to(torch.int64), minlength=n_src), 0)
         del key, d, order
-        return cls(n_dst, n_src, rowptr.cpu().numpy(), col, colptr.cpu().numpy(), rowidx, perm, dev, chunk)
+        return cls(n_dst, n_src, rowptr.cpu().numpy(), col, colptr.cpu().numpy(), rowidx, perm, dev, chunk, item_order)
+
+    @classmethod
+    def from_bias_mat(cls, bias_mat, cutoff=1.0e6):
+        """A batch of dense additive masks [B,N,N] (adj_to_bias, utils/process.py:14-25) as ONE
+        block-diagonal graph over B*N nodes: entry (b,i,j) is kept iff it lies within `cutoff` of its
+        row's maximum (anything lower has a softmax coefficient of exactly 0 in fp32).  Build it
+        once for a mask that is used step after step and pass it where bias_mat went: the layer then
+        runs the CSR kernels and never reads the N x N floats again.  Only for hard masks: every kept
+        entry must be 0 (a kept non-zero bias would have to be added to the logits, which the CSR
+        kernels do not do) -- ValueError otherwise."""
+        if bias_mat.dim() != 3 or bias_mat.shape[1] != bias_mat.shape[2] or not bias_mat.is_cuda:
+            raise ValueError("from_bias_mat: a [B,N,N] device tensor is expected")
+        B, N, _ = bias_mat.shape
+        keep = bias_mat > bias_mat.amax(-1, keepdim=True) - cutoff
+        if bool((bias_mat[keep] != 0).any()):
+            raise ValueError("from_bias_mat: the mask carries non-zero biases on entries that contribute; "
+                             "keep it dense (attn_head adds them to the logits)")
+        b, i, j = keep.nonzero(as_tuple=True)
+        del keep
+        base = b * N
+        return cls.from_device_coo(base + i, base + j, B * N, B * N, max(MIN_CHUNK, 1 << (N - 1).bit_length()), item_order="rows")
 
     # ---- helpers ------------------------------------------------------------------------------
     def in_degrees(self):

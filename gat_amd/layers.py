@@ -82,8 +82,14 @@ class GATHeads(nn.Module):
         training = self.training if training is None else training
         H, D = self.heads, self.width
         act = _activation_name(activation)
-        if isinstance(graph_or_bias, CSRGraph) and seq.dim() == 3:           # batch is 1 on the sparse path
-            return self.forward(seq[0], graph_or_bias, act, reduce, in_drop, coef_drop, training, seed)[None]
+        if isinstance(graph_or_bias, CSRGraph) and seq.dim() == 3:
+            # the sparse path of the reference has batch 1; a batch of small graphs may come with ONE
+            # block-diagonal graph over all B*N nodes (CSRGraph.from_bias_mat)
+            B, N = seq.shape[:2]
+            if B * N != graph_or_bias.n_dst:
+                raise ValueError("seq is [%d,%d,.] but the graph has %d nodes" % (B, N, graph_or_bias.n_dst))
+            out = self.forward(seq.reshape(B * N, -1), graph_or_bias, act, reduce, in_drop, coef_drop, training, seed)
+            return out.reshape(B, N, -1)
         if isinstance(seq, SparseFeatures):                                  # sparse node features stand for [1,N,F]
             if not isinstance(graph_or_bias, CSRGraph):
                 raise ValueError("sparse node features go with the sparse attention head (sp_attn_head)")

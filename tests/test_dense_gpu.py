@@ -175,3 +175,32 @@ def test_padded_batch_with_per_graph_sizes(path):
     assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what="padded dX")
     for k in ("W", "a1", "a2", "bias"):
         assert_close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), atol_scale=5e-6, what="padded d" + k)
+
+
+def test_hard_mask_as_block_diagonal_graph():
+    """CSRGraph.from_bias_mat: a batch of adj_to_bias masks converted once into one graph over B*N
+    nodes; GATHeads then runs the CSR kernels on [B,N,F] input and matches the dense route.  Soft
+    masks are refused (their biases would be lost)."""
+    from gat_amd import CSRGraph
+    from gat_amd.layers import GATHeads
+    dev = torch.device("cuda:0")
+    B, N, F, H, D = 5, 70, 9, 8, 8
+    bm = torch.tensor(_masks(B, N, 0.12, 21), dtype=torch.float32, device=dev)
+    x = torch.tensor(np.random.default_rng(3).normal(0, 1, (B, N, F)), dtype=torch.float32, device=dev, requires_grad=True)
+    m = GATHeads(F, H, D, device=dev)
+    m.load(layer_params(F, H, D, seed=4))
+    graph = CSRGraph.from_bias_mat(bm)
+    assert graph.n_dst == B * N and graph.nnz == int((bm > -1e8).sum()) and len(graph.split_csr) == 0
+    assert (graph.items_csr[:, 0].cpu().numpy() == np.arange(B * N)).all()           # rows in their own order
+    a = m(x, graph, "elu")
+    ga = torch.autograd.grad(a.square().sum(), [x, m.W, m.a1])
+    b = m(x, bm, "elu")
+    gb = torch.autograd.grad(b.square().sum(), [x, m.W, m.a1])
+    assert tuple(a.shape) == (B, N, H * D)
+    assert_close(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-6, atol_scale=1e-6, what="graph vs mask")
+    for u, v, name in zip(ga, gb, ("dX", "dW", "da1")):
+        assert_close(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-5, atol_scale=5e-6, what="graph vs mask " + name)
+    with pytest.raises(ValueError):
+        CSRGraph.from_bias_mat(torch.tensor(_masks(1, 20, 0.2, 2, soft=True), dtype=torch.float32, device=dev))
+    with pytest.raises(ValueError):
+        m(x[:, :10], graph, "elu")

@@ -199,3 +199,25 @@ def test_training_step_replays_from_a_hip_graph():
     step()
     torch.cuda.synchronize()
     assert torch.equal(a, static_out)
+
+
+def test_gat_inference_accepts_a_prebuilt_graph_for_bias_mat():
+    """GAT.inference on a batch of small graphs with bias_mat replaced by the block-diagonal graph
+    built once from it (CSRGraph.from_bias_mat): same logits, mean over the output heads included."""
+    from gat_amd import CSRGraph, layers, preprocess
+    from gat_amd.models import GAT
+    dev = torch.device("cuda:0")
+    B, N, F, C = 6, 40, 11, 5
+    rng = np.random.default_rng(0)
+    adj = (rng.random((B, N, N)) < 0.1).astype(np.float64)
+    bm = torch.tensor(preprocess.adj_to_bias(adj, [N] * B, 1), dtype=torch.float32, device=dev)
+    x = torch.tensor(rng.normal(0, 1, (B, N, F)), dtype=torch.float32, device=dev)
+    store = layers.VariableStore()
+    kw = dict(hid_units=[8, 8], n_heads=[4, 2, 2], activation=layers.elu, residual=True)
+    with layers.variable_scope(store):
+        a = GAT.inference(x, C, N, False, 0.0, 0.0, bias_mat=bm, **kw)
+        _randomise_biases(store, 2)
+        a = GAT.inference(x, C, N, False, 0.0, 0.0, bias_mat=bm, **kw)
+        b = GAT.inference(x, C, N, False, 0.0, 0.0, bias_mat=CSRGraph.from_bias_mat(bm), **kw)
+    assert tuple(b.shape) == (B, N, C)
+    assert_close(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=5e-6, atol_scale=2e-6, what="graph for bias_mat")
