@@ -360,7 +360,7 @@ constexpr int kNodeChunk = 64;
 
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void xt_gemm_kernel(const float *X, int64_t n, int F, int64_t ldx,
-                                                       const float *dY, int hd, float *ws) {
+                                                       const float *dY, int ldy, int hd, float *ws) {
     __shared__ float red[MT * 16 * (NT * 16 + 1)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void xt_gemm_kernel(const float *X, int64_t n,
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[mt] = (nok && fok[mt]) ? X[node * ldx + fcol[mt]] : 0.f;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = (nok && yok[nt]) ? dY[node * hd + ycol[nt]] : 0.f;
+            for (int nt = 0; nt < NT; ++nt) b[nt] = (nok && yok[nt]) ? dY[node * ldy + ycol[nt]] : 0.f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -508,12 +508,13 @@ __global__ __launch_bounds__(256, 2) void xt_gemm_lines_kernel(const float *X, i
 }
 
 // dW[f][c] = sum_b ws[b][f][c]   (f < F, c < hd; ws rows are NT16 wide)
-__global__ void reduce_dw_kernel(const float *ws, int nblocks, int Fp, int NT16, int F, int hd, float *dW) {
+// dW[f, c] (row stride ldw) = sum over blocks of ws[b][f][c] for f < F, c < hd
+__global__ void reduce_dw_kernel(const float *ws, int nblocks, int Fp, int NT16, int F, int hd, int ldw, float *dW) {
     const int e = blockIdx.x * kSumCols + threadIdx.x;
     const bool ok = e < F * hd;
     const int f = ok ? e / hd : 0, c = ok ? e % hd : 0;
     const float t = block_column_sum(nblocks, [&](int b) { return ok ? ws[((int64_t)b * Fp + f) * NT16 + c] : 0.f; });
-    if (ok && threadIdx.y == 0) dW[e] = t;
+    if (ok && threadIdx.y == 0) dW[(int64_t)f * ldw + c] = t;
 }
 
 // da1 = sum_i df1[i,h] Wh[i,h,:], da2 likewise with df2, db1 = sum_i df1, db2 = sum_i df2.
@@ -636,25 +637,25 @@ static int launch_xt_lines(const float *X, int64_t n, int F, int64_t ldx, const 
     else hipLaunchKernelGGL(xt_gemm_lines_kernel<2>, grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws);
     GATMI_LAUNCH_CHECK("xt_gemm_lines");
     hipLaunchKernelGGL(reduce_dw_kernel, dim3((F * hd + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, ws, (int)gx,
-                       (int)(gy * 64 * FS), (int)(gz * 64), F, hd, dW);
+                       (int)(gy * 64 * FS), (int)(gz * 64), F, hd, hd, dW);
     GATMI_LAUNCH_CHECK("reduce_dw");
     return GATMI_OK;
 }
 
 template <int MT>
-static int launch_xt_gemm(const float *X, int64_t n, int F, int64_t ldx, const float *dY, int hd, float *ws,
+static int launch_xt_gemm(const float *X, int64_t n, int F, int64_t ldx, const float *dY, int ldy, int hd, float *ws,
                           float *dW, hipStream_t st) {
     const int NT = (hd + 15) / 16;
     const unsigned gy = (unsigned)((F + MT * 16 - 1) / (MT * 16));
     const unsigned gx = (unsigned)std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 4 * kNodeChunk - 1) / (4 * kNodeChunk)));
     const dim3 grid(gx, gy);
     int nt_pad;
-    if (NT <= 1) { nt_pad = 1; hipLaunchKernelGGL((xt_gemm_kernel<MT, 1>), grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws); }
-    else if (NT <= 2) { nt_pad = 2; hipLaunchKernelGGL((xt_gemm_kernel<MT, 2>), grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws); }
-    else { nt_pad = 4; hipLaunchKernelGGL((xt_gemm_kernel<MT, 4>), grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws); }
+    if (NT <= 1) { nt_pad = 1; hipLaunchKernelGGL((xt_gemm_kernel<MT, 1>), grid, dim3(256), 0, st, X, n, F, ldx, dY, ldy, hd, ws); }
+    else if (NT <= 2) { nt_pad = 2; hipLaunchKernelGGL((xt_gemm_kernel<MT, 2>), grid, dim3(256), 0, st, X, n, F, ldx, dY, ldy, hd, ws); }
+    else { nt_pad = 4; hipLaunchKernelGGL((xt_gemm_kernel<MT, 4>), grid, dim3(256), 0, st, X, n, F, ldx, dY, ldy, hd, ws); }
     GATMI_LAUNCH_CHECK("xt_gemm");
     const int Fp = gy * MT * 16;
-    hipLaunchKernelGGL(reduce_dw_kernel, dim3((F * hd + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, ws, (int)gx, Fp, nt_pad * 16, F, hd, dW);
+    hipLaunchKernelGGL(reduce_dw_kernel, dim3((F * hd + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, ws, (int)gx, Fp, nt_pad * 16, F, hd, ldy, dW);
     GATMI_LAUNCH_CHECK("reduce_dw");
     return GATMI_OK;
 }
@@ -809,15 +810,15 @@ extern "C" int gatmi_proj_bwd_params(const float *X, int64_t n, int32_t f_in, in
     }
     if (ldx % 4 == 0 && f_in % 4 == 0 && aligned16(X) && aligned16(dWh) && f_in <= 1024)
         return launch_xt_lines(X, n, f_in, ldx, dWh, hd, ws, dW, st);
-    // dW in column slabs of 64 (one slab for hd <= 64)
+    // rows of X that are not 16-byte aligned: dW in column slabs of 64 (one slab for hd <= 64); the
+    // slabs share the workspace, which the stream order makes safe
     for (int c0 = 0; c0 < hd; c0 += 64) {
         const int w = std::min(64, hd - c0);
-        GATMI_REQUIRE(c0 == 0, GATMI_EUNSUPPORTED, "proj_bwd_params: hd=%d > 64 not built yet (slab of %d)", hd, w);
         switch (dw_mt(f_in)) {
-            case 1: rc = launch_xt_gemm<1>(X, n, f_in, ldx, dWh, hd, ws, dW, st); break;
-            case 2: rc = launch_xt_gemm<2>(X, n, f_in, ldx, dWh, hd, ws, dW, st); break;
-            case 4: rc = launch_xt_gemm<4>(X, n, f_in, ldx, dWh, hd, ws, dW, st); break;
-            default: rc = launch_xt_gemm<7>(X, n, f_in, ldx, dWh, hd, ws, dW, st); break;
+            case 1: rc = launch_xt_gemm<1>(X, n, f_in, ldx, dWh + c0, hd, w, ws, dW + c0, st); break;
+            case 2: rc = launch_xt_gemm<2>(X, n, f_in, ldx, dWh + c0, hd, w, ws, dW + c0, st); break;
+            case 4: rc = launch_xt_gemm<4>(X, n, f_in, ldx, dWh + c0, hd, w, ws, dW + c0, st); break;
+            default: rc = launch_xt_gemm<7>(X, n, f_in, ldx, dWh + c0, hd, w, ws, dW + c0, st); break;
         }
         if (rc) return rc;
     }

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("n,F,H,D", [(5000, 100, 8, 8), (4100, 36, 1, 7), (6000, 128, 4, 16), (4500, 8, 2, 4),
-                                     (3000, 100, 8, 8), (2708, 1433, 8, 8), (700, 130, 1, 64), (5000, 52, 8, 8)])
+                                     (3000, 100, 8, 8), (2708, 1433, 8, 8), (700, 130, 1, 64), (5000, 52, 8, 8),
+                                     (1500, 33, 16, 8), (900, 1433, 4, 64), (1200, 64, 8, 32), (800, 7, 2, 64)])
 def test_projection_forward_and_backward(n, F, H, D):
     from gat_amd import _lib, ops
     from gat_amd._lib import ptr
