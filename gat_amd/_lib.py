@@ -78,7 +78,7 @@ for _name, (_res, _args) in _SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ACT_IDENTITY, ACT_ELU, ACT_SIGMOID = 0, 1, 2
+ACT_IDENTITY, ACT_ELU, ACT_SIGMOID, ACT_RELU = 0, 1, 2, 3
 DTYPE_F32, DTYPE_BF16 = 0, 1
 REDUCE_CONCAT, REDUCE_MEAN = 0, 1
 

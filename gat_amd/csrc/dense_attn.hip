@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_kernel(DenseFwdArgs a) {
                         float v = ag;
                         if (a.bias) v += a.bias[hg * DP + c];
                         if (a.resid) v += a.resid[o];
-                        if (a.activation == GATMI_ACT_ELU) v = elu_f(v);
+                        v = act_f(v, a.activation);
                         a.out[o] = v;
                     }
                 }
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_hg_kernel(DenseFwdArgs a) 
                             float v = ag;
                             if (a.bias) v += a.bias[hg * DP + c];
                             if (a.resid) v += a.resid[o];
-                            if (a.activation == GATMI_ACT_ELU) v = elu_f(v);
+                            v = act_f(v, a.activation);
                             a.out[o] = v;
                         }
                     }
@@ -715,7 +715,7 @@ extern "C" int gatmi_dense_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t dp,
     if (B == 0 || N == 0) return GATMI_OK;
     GATMI_REQUIRE(B <= 0x7fffffff, GATMI_ERANGE, "dense_attn_fwd: batch %lld too large for one launch", (long long)B);
     GATMI_REQUIRE(Wh && f1 && f2 && bias_mat && out, GATMI_EINVAL, "dense_attn_fwd: null pointer");
-    GATMI_REQUIRE(activation == GATMI_ACT_IDENTITY || activation == GATMI_ACT_ELU, GATMI_EUNSUPPORTED, "dense_attn_fwd: activation %d", activation);
+    GATMI_REQUIRE(act_known(activation), GATMI_EUNSUPPORTED, "dense_attn_fwd: activation %d", activation);
     const bool save = agg || pos || lse || q;
     GATMI_REQUIRE(!save || (agg && pos && lse && q), GATMI_EINVAL, "dense_attn_fwd: agg, pos, lse, q must be given together");
     GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "dense_attn_fwd: keep probabilities must be in (0,1]");

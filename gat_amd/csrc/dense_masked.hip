@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, GATMI_MASK_MINBLOCKS) void dense_masked_fwd_ke
     float4 r = ag;
     if (a.bias) r = f4_add(r, *reinterpret_cast<const float4 *>(a.bias + sub * 4));
     if (a.resid) r = f4_add(r, *reinterpret_cast<const float4 *>(a.resid + row * HD + sub * 4));
-    if (a.activation == GATMI_ACT_ELU) r = make_float4(elu_f(r.x), elu_f(r.y), elu_f(r.z), elu_f(r.w));
+    if (a.activation != GATMI_ACT_IDENTITY) r = make_float4(act_f(r.x, a.activation), act_f(r.y, a.activation), act_f(r.z, a.activation), act_f(r.w, a.activation));
     *reinterpret_cast<float4 *>(a.out + row * HD + sub * 4) = r;
 }
 
@@ -539,7 +539,7 @@ extern "C" int gatmi_dense_attn_fwd_masked(int64_t B, int32_t N, int32_t H, int3
     if (rc) return rc;
     if (B == 0 || N == 0) return GATMI_OK;
     GATMI_REQUIRE(Wh && f1 && f2 && bias_mat && out, GATMI_EINVAL, "dense_attn_fwd_masked: null pointer");
-    GATMI_REQUIRE(activation == GATMI_ACT_IDENTITY || activation == GATMI_ACT_ELU, GATMI_EUNSUPPORTED, "dense_attn_fwd_masked: activation %d", activation);
+    GATMI_REQUIRE(act_known(activation), GATMI_EUNSUPPORTED, "dense_attn_fwd_masked: activation %d", activation);
     const bool save = agg || pos || lse || q;
     GATMI_REQUIRE(!save || (agg && pos && lse && q), GATMI_EINVAL, "dense_attn_fwd_masked: agg, pos, lse, q must be given together");
     GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "dense_attn_fwd_masked: keep probabilities must be in (0,1]");

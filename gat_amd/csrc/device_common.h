@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/gatmi.h"
+
 namespace gatmi {
 
 constexpr float kLog2e = 1.4426950408889634f;
@@ -83,6 +85,17 @@ __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x)
 
 // derivative of ELU written in terms of its OUTPUT y: 1 for y > 0, y + 1 (= exp(x)) otherwise
 __device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
+
+// the layer's output activation (utils/layers.py:34) and its derivative in terms of the output
+__device__ __forceinline__ float act_f(float x, int activation) {
+    return activation == GATMI_ACT_ELU ? elu_f(x) : (activation == GATMI_ACT_RELU ? fmaxf(x, 0.f) : x);
+}
+__device__ __forceinline__ float act_grad_from_out(float y, int activation) {
+    return activation == GATMI_ACT_ELU ? elu_grad_from_out(y) : (activation == GATMI_ACT_RELU ? (y > 0.f ? 1.f : 0.f) : 1.f);
+}
+__host__ __device__ inline bool act_known(int activation) {
+    return activation == GATMI_ACT_IDENTITY || activation == GATMI_ACT_ELU || activation == GATMI_ACT_RELU;
+}
 
 // bf16 storage of gathered tables: two values per dword, element 0 in the low half.
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {

@@ -136,7 +136,7 @@ __device__ __forceinline__ void fwd_finish(const RowState &st, const FwdArgs &a,
         return;
     }
     if (a.resid) r = f4_add(r, *reinterpret_cast<const float4 *>(a.resid + row * HD + sub * 4));
-    if (a.activation == GATMI_ACT_ELU) r = make_float4(elu_f(r.x), elu_f(r.y), elu_f(r.z), elu_f(r.w));
+    if (a.activation != GATMI_ACT_IDENTITY) r = make_float4(act_f(r.x, a.activation), act_f(r.y, a.activation), act_f(r.z, a.activation), act_f(r.w, a.activation));
     *reinterpret_cast<float4 *>(a.out + row * HD + sub * 4) = r;
 }
 
@@ -250,12 +250,12 @@ __global__ __launch_bounds__(256) void gat_bwd_node_kernel(BwdNodeArgs a) {
             gv = f4_scale(1.0f / H, *reinterpret_cast<const float4 *>(a.dout + row * (4 * LPH) + (sub % LPH) * 4));
         } else {
             gv = *reinterpret_cast<const float4 *>(a.dout + row * HD + sub * 4);
-            if (a.activation == GATMI_ACT_ELU) {
+            if (a.activation != GATMI_ACT_IDENTITY) {
                 const float4 o = *reinterpret_cast<const float4 *>(a.out + row * HD + sub * 4);
-                gv.x *= elu_grad_from_out(o.x);
-                gv.y *= elu_grad_from_out(o.y);
-                gv.z *= elu_grad_from_out(o.z);
-                gv.w *= elu_grad_from_out(o.w);
+                gv.x *= act_grad_from_out(o.x, a.activation);
+                gv.y *= act_grad_from_out(o.y, a.activation);
+                gv.z *= act_grad_from_out(o.z, a.activation);
+                gv.w *= act_grad_from_out(o.w, a.activation);
             }
         }
         const float4 ag = *reinterpret_cast<const float4 *>(a.agg + row * HD + sub * 4);
@@ -589,7 +589,7 @@ extern "C" int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
     GATMI_REQUIRE(items && feat && f1 && f2 && out, GATMI_EINVAL, "gat_fwd: null pointer");
     GATMI_REQUIRE(n_items >= n_dst, GATMI_EINVAL, "gat_fwd: %lld work items for %lld rows (every row needs an item)", (long long)n_items, (long long)n_dst);
     GATMI_REQUIRE(n_split == 0 || (split && ws), GATMI_EINVAL, "gat_fwd: split rows need `split` and `ws`");
-    GATMI_REQUIRE(activation == GATMI_ACT_IDENTITY || activation == GATMI_ACT_ELU, GATMI_EUNSUPPORTED, "gat_fwd: activation %d", activation);
+    GATMI_REQUIRE(act_known(activation), GATMI_EUNSUPPORTED, "gat_fwd: activation %d", activation);
     GATMI_REQUIRE(reduce == GATMI_REDUCE_CONCAT || (reduce == GATMI_REDUCE_MEAN && activation == GATMI_ACT_IDENTITY), GATMI_EUNSUPPORTED,
                   "gat_fwd: reduce %d with activation %d (mean over heads needs the identity activation)", reduce, activation);
     GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "gat_fwd: keep probabilities must be in (0,1]");
@@ -629,7 +629,7 @@ extern "C" int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
     GATMI_REQUIRE(n_dst >= 0, GATMI_EINVAL, "gat_bwd_node: negative size");
     GATMI_REQUIRE(dout && agg && pos && q && f1 && lse && (g || g16) && stats && df1 && ws, GATMI_EINVAL, "gat_bwd_node: null pointer");
     GATMI_REQUIRE_ALIGNED(g16);
-    GATMI_REQUIRE(activation == GATMI_ACT_IDENTITY || (activation == GATMI_ACT_ELU && out), GATMI_EUNSUPPORTED, "gat_bwd_node: activation %d (ELU needs `out`)", activation);
+    GATMI_REQUIRE(activation == GATMI_ACT_IDENTITY || (act_known(activation) && out), GATMI_EUNSUPPORTED, "gat_bwd_node: activation %d (ELU and ReLU need `out`)", activation);
     GATMI_REQUIRE(reduce == GATMI_REDUCE_CONCAT || (reduce == GATMI_REDUCE_MEAN && activation == GATMI_ACT_IDENTITY), GATMI_EUNSUPPORTED, "gat_bwd_node: reduce %d", reduce);
     GATMI_REQUIRE_ALIGNED(dout); GATMI_REQUIRE_ALIGNED(out); GATMI_REQUIRE_ALIGNED(agg); GATMI_REQUIRE_ALIGNED(pos);
     GATMI_REQUIRE_ALIGNED(g); GATMI_REQUIRE_ALIGNED(ws);

@@ -28,14 +28,14 @@ identity = "identity"
 
 def _activation_name(activation):
     """Accept the reference's callables (tf.nn.elu, lambda x: x) by name, or our string names."""
-    if activation in ("elu", "identity", None):
+    if activation in ("elu", "relu", "identity", None):
         return activation or "identity"
     name = getattr(activation, "__name__", "")
-    if name == "elu":
-        return "elu"
+    if name in ("elu", "relu"):
+        return name
     if name == "<lambda>" or name == "identity":
         return "identity"
-    raise ValueError("unsupported activation %r: the kernels fuse ELU or the identity" % (activation,))
+    raise ValueError("unsupported activation %r: the kernels fuse ELU, ReLU or the identity" % (activation,))
 
 
 class GATHeads(nn.Module):

@@ -13,7 +13,7 @@ from .features import SparseFeatures
 
 LEAKY_SLOPE = 0.2  # tf.nn.leaky_relu default, utils/layers.py:17
 
-_ACT = {"elu": _lib.ACT_ELU, "identity": _lib.ACT_IDENTITY, None: _lib.ACT_IDENTITY}
+_ACT = {"elu": _lib.ACT_ELU, "relu": _lib.ACT_RELU, "identity": _lib.ACT_IDENTITY, None: _lib.ACT_IDENTITY}
 _RED = {"concat": _lib.REDUCE_CONCAT, "mean": _lib.REDUCE_MEAN}
 
 
@@ -338,7 +338,7 @@ def make_cfg(H, D, activation="elu", reduce="concat", coef_drop=0.0, in_drop=0.0
     only): "auto" picks the compacted-list kernels for sparse masks and the matrix-core kernels for
     dense ones; "lists" / "dense" force one of them (same results)."""
     if activation not in _ACT:
-        raise ValueError("activation must be 'elu' or 'identity', got %r" % (activation,))
+        raise ValueError("activation must be 'elu', 'relu' or 'identity', got %r" % (activation,))
     if not supported_shape(H, D):
         raise ValueError("heads=%d width=%d: the fused kernels need a power-of-two head count and heads * "
                          "padded width <= 256; call the layer per head instead" % (H, D))

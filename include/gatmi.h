@@ -47,6 +47,7 @@ extern "C" {
 #define GATMI_ACT_IDENTITY 0    /* `lambda x: x`, models/sp_gat.py:30 */
 #define GATMI_ACT_ELU      1    /* tf.nn.elu,     models/sp_gat.py:9  */
 #define GATMI_ACT_SIGMOID  2    /* tf.nn.sigmoid, utils/layers.py:307 (inner-product decoder only) */
+#define GATMI_ACT_RELU     3    /* tf.nn.relu, the `activation` of the brain-network models (models/gat.py:191) */
 
 #define GATMI_DTYPE_F32  0      /* storage of a gathered table: fp32 rows ...                      */
 #define GATMI_DTYPE_BF16 1      /* ... or bf16 rows (half the gather traffic; arithmetic stays fp32) */

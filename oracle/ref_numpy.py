@@ -33,6 +33,11 @@ def identity(x):
     return x
 
 
+def relu(x):
+    """tf.nn.relu, the activation the brain-network models pass (models/gat.py:191)."""
+    return np.maximum(x, 0)
+
+
 def leaky_relu(x, slope=LEAKY_SLOPE):
     return np.where(x > 0, x, slope * x)
 

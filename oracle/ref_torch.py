@@ -15,6 +15,8 @@ LEAKY_SLOPE = 0.2  # tf.nn.leaky_relu default, utils/layers.py:17
 def _act(name):
     if name == "elu":
         return F.elu
+    if name == "relu":
+        return F.relu
     if name in ("identity", "none", None):
         return lambda x: x
     raise ValueError(name)

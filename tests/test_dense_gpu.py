@@ -33,6 +33,7 @@ CASES = [
     (1, 530, 8, 1, 64, "identity", False),  # same for a single wide head
     (3, 300, 10, 4, 8, "elu", True),        # 32-float rows: 8 lanes per row in the list kernels, two list passes
     (1, 70, 8, 4, 64, "elu", False),        # 256-float rows: one row per wave
+    (2, 90, 7, 8, 8, "relu", False),
 ]
 
 
@@ -55,7 +56,7 @@ def test_dense_layer_forward_and_gradients(B, N, F, H, D, activation, soft, path
     cfg = ops.make_cfg(H, D, activation=activation, mask_path=path)
     out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"],
                               torch.tensor(bm, dtype=torch.float32, device=dev), cfg, tp.get("W_res"), tp.get("b_res"))
-    act = ref_numpy.elu if activation == "elu" else ref_numpy.identity
+    act = {"elu": ref_numpy.elu, "relu": ref_numpy.relu, "identity": ref_numpy.identity}[activation]
     ref = ref_numpy.gat_layer_dense(x, p, bm, act, "concat", residual="W_res" in p)
     assert_close(out.detach().cpu().numpy(), ref, what="dense forward")
 

@@ -64,6 +64,7 @@ CASES = [
     (128, 64, 1, 64, 5.0, "elu", "concat"),
     (200, 12, 2, 16, 3.0, "elu", "concat"),
     (150, 10, 8, 4, 5.0, "identity", "mean"),
+    (210, 14, 8, 8, 6.0, "relu", "concat"),
 ]
 
 
@@ -71,7 +72,7 @@ CASES = [
 def test_forward_matches_float64_oracle(n, F, H, D, deg, activation, reduce):
     dst, src = random_graph(n, deg, seed=n)
     x, p, tp, xt, out, rowptr, col = _run_layer(n, F, H, D, dst, src, activation, reduce, seed=n + 7)
-    act = ref_numpy.elu if activation == "elu" else ref_numpy.identity
+    act = {"elu": ref_numpy.elu, "relu": ref_numpy.relu, "identity": ref_numpy.identity}[activation]
     ref = ref_numpy.gat_layer_csr(x, p, rowptr, col, activation=act, reduce=reduce)
     assert_close(out.detach().cpu().numpy(), ref, what="forward")
 
