@@ -10,6 +10,8 @@
 // and one transposed read of dOut and one read of the saved output; Zd chunks are the B operand.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "common.h"
 #include "device_common.h"
 
@@ -152,6 +154,133 @@ __global__ __launch_bounds__(256) void ipd_bwd_kernel(IpdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Small graphs (the whole Zd of a graph fits LDS next to a second block): block (graph b, split y)
+// stages Zd once, then its eight waves need no barrier.  Forward: the (row tile, column tile) pairs
+// are dealt to the waves in contiguous runs, so a wave keeps its A operand over a run and writes
+// neighbouring 64-byte segments of the same output rows.  Backward: a wave owns row tiles and takes
+// two column tiles per step, all 24 loads of a step in flight before its MFMAs.
+// ------------------------------------------------------------------------------------------
+constexpr int kGraphWaves = 8;
+constexpr size_t kGraphLdsMax = 80 * 1024;
+
+template <int NTF>
+__device__ __forceinline__ void ipd_stage_graph(const IpdArgs &a, int64_t b, int Np, float *zs) {
+    using S = IpdShape<NTF>;
+    for (int e = threadIdx.x; e < Np * S::FP; e += 64 * kGraphWaves) {
+        const int r = e / S::FP, c = e % S::FP;
+        float v = 0.f;
+        if (r < a.N && c < a.F) v = ipd_load(a, b * a.N + r, c);
+        zs[r * S::LD + c] = v;
+    }
+}
+
+template <int NTF>
+__global__ __launch_bounds__(64 * kGraphWaves) void ipd_fwd_graph_kernel(IpdArgs a) {
+    using S = IpdShape<NTF>;
+    extern __shared__ __attribute__((aligned(16))) float zs_graph[];
+    float *zs = zs_graph;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int N = a.N, Np = (N + 15) & ~15, nt = Np / 16;
+    const int64_t b = blockIdx.x;
+    ipd_stage_graph<NTF>(a, b, Np, zs);
+    __syncthreads();
+    const int n_pairs = nt * nt;
+    const int n_waves = gridDim.y * kGraphWaves;
+    const int per = (n_pairs + n_waves - 1) / n_waves;
+    const int w = blockIdx.y * kGraphWaves + wave;
+    const int p_end = min(n_pairs, (w + 1) * per);
+    int cur = -1;
+    float av[S::KS];
+    for (int p = w * per; p < p_end; ++p) {
+        const int it = p / nt, jt = p - it * nt;
+        if (it != cur) {
+            cur = it;
+            const float *ar = zs + (16 * it + m) * S::LD + kq;
+#pragma unroll
+            for (int s = 0; s < S::KS; ++s) av[s] = ar[4 * s];
+        }
+        f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float *zr = zs + (16 * jt + m) * S::LD + kq;
+#pragma unroll
+        for (int s = 0; s < S::KS; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], zr[4 * s], c, 0, 0, 0);
+        const int j = 16 * jt + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * it + 4 * kq + r;
+            if (i < N && j < N) {
+                float v = c[r];
+                if (a.activation == GATMI_ACT_SIGMOID) v = __builtin_amdgcn_rcpf(1.f + __expf(-v));
+                a.out[(b * N + i) * (int64_t)N + j] = v;
+            }
+        }
+    }
+}
+
+template <int NTF>
+__global__ __launch_bounds__(64 * kGraphWaves) void ipd_bwd_graph_kernel(IpdArgs a) {
+    using S = IpdShape<NTF>;
+    extern __shared__ __attribute__((aligned(16))) float zs_graph[];
+    float *zs = zs_graph;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int N = a.N, Np = (N + 15) & ~15, nt = Np / 16;
+    const int64_t b = blockIdx.x;
+    ipd_stage_graph<NTF>(a, b, Np, zs);
+    __syncthreads();
+    const float *gmat = a.dOut + b * N * (int64_t)N;
+    const float *omat = a.out_saved ? a.out_saved + b * N * (int64_t)N : nullptr;
+    for (int it = blockIdx.y * kGraphWaves + wave; it < nt; it += gridDim.y * kGraphWaves) {
+        const int i0 = 16 * it;
+        const bool iok = i0 + m < N;
+        const uint32_t irow = (uint32_t)min(i0 + m, N - 1);
+        f32x4 acc[NTF];
+#pragma unroll
+        for (int nt_ = 0; nt_ < NTF; ++nt_) acc[nt_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < Np; j0 += 32) {
+            float gd[2][4], gt[2][4], ov[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const uint32_t j = (uint32_t)min(j0 + 16 * h + 4 * kq + s, N - 1);
+                    gd[h][s] = gmat[irow * (uint32_t)N + j];
+                    gt[h][s] = gmat[j * (uint32_t)N + irow];
+                    ov[h][s] = omat ? omat[irow * (uint32_t)N + j] : 0.5f;
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (j0 + 16 * h >= Np) break;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int j = j0 + 16 * h + 4 * kq + s;
+                    float v = gd[h][s] + gt[h][s];
+                    if (omat) v *= ov[h][s] * (1.f - ov[h][s]);
+                    if (!(iok && j < N)) v = 0.f;
+                    const float *zr = zs + j * S::LD + m;
+#pragma unroll
+                    for (int nt_ = 0; nt_ < NTF; ++nt_) acc[nt_] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, zr[16 * nt_], acc[nt_], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 4 * kq + r;
+            if (i >= N) continue;
+#pragma unroll
+            for (int nt_ = 0; nt_ < NTF; ++nt_) {
+                const int c = 16 * nt_ + m;
+                if (c < a.F) {
+                    float v = acc[nt_][r];
+                    if (a.keep < 1.f) v = drop_feat1(v, a.seed, b * N + i, a.F, c, a.keep);
+                    a.dZ[(b * N + i) * (int64_t)a.F + c] = v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace gatmi
 
 using namespace gatmi;
@@ -166,15 +295,36 @@ static int ipd_check(int64_t B, int32_t N, int32_t F, int32_t activation, float 
     return GATMI_OK;
 }
 
-#define GATMI_IPD_LAUNCH(kernel, name)                                                      \
+// kernel: the chunked kernel (any N); gkernel: the whole-graph kernel, taken when the graph's Zd fits
+// kGraphLdsMax bytes of LDS (N * 64 <= 2^31 there, so 32-bit offsets inside a graph are safe)
+#define GATMI_IPD_LAUNCH(kernel, gkernel, name)                                             \
     do {                                                                                    \
-        const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64));                            \
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);                             \
         const int ntf = (F + 15) / 16;                                                      \
-        if (ntf <= 1) hipLaunchKernelGGL((kernel<1>), grid, dim3(256), 0, st, a);           \
-        else if (ntf <= 2) hipLaunchKernelGGL((kernel<2>), grid, dim3(256), 0, st, a);      \
-        else if (ntf <= 4) hipLaunchKernelGGL((kernel<4>), grid, dim3(256), 0, st, a);      \
-        else hipLaunchKernelGGL((kernel<8>), grid, dim3(256), 0, st, a);                    \
+        const int ntf_pad = ntf <= 1 ? 1 : (ntf <= 2 ? 2 : (ntf <= 4 ? 4 : 8));             \
+        const int np = (N + 15) & ~15;                                                      \
+        const size_t lds = (size_t)np * (size_t)(16 * ntf_pad + 4) * sizeof(float);         \
+        if (lds <= kGraphLdsMax) {                                                          \
+            const int tiles = np / 16;                                                      \
+            const int splits = (int)std::max<int64_t>(1, std::min<int64_t>((tiles + kGraphWaves - 1) / kGraphWaves, 2048 / std::max<int64_t>(B, 1))); \
+            const dim3 grid((unsigned)B, (unsigned)splits);                                 \
+            hipError_t e = hipSuccess;                                                      \
+            if (ntf_pad == 1) { if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gkernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                                if (e == hipSuccess) hipLaunchKernelGGL((gkernel<1>), grid, dim3(64 * kGraphWaves), lds, st, a); }  \
+            else if (ntf_pad == 2) { if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gkernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                                if (e == hipSuccess) hipLaunchKernelGGL((gkernel<2>), grid, dim3(64 * kGraphWaves), lds, st, a); }  \
+            else if (ntf_pad == 4) { if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gkernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                                if (e == hipSuccess) hipLaunchKernelGGL((gkernel<4>), grid, dim3(64 * kGraphWaves), lds, st, a); }  \
+            else { if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gkernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                                if (e == hipSuccess) hipLaunchKernelGGL((gkernel<8>), grid, dim3(64 * kGraphWaves), lds, st, a); }  \
+            if (e != hipSuccess) return fail(GATMI_EHIP, "%s: %s", name, hipGetErrorString(e)); \
+        } else {                                                                            \
+            const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64));                        \
+            if (ntf_pad == 1) hipLaunchKernelGGL((kernel<1>), grid, dim3(256), 0, st, a);   \
+            else if (ntf_pad == 2) hipLaunchKernelGGL((kernel<2>), grid, dim3(256), 0, st, a); \
+            else if (ntf_pad == 4) hipLaunchKernelGGL((kernel<4>), grid, dim3(256), 0, st, a); \
+            else hipLaunchKernelGGL((kernel<8>), grid, dim3(256), 0, st, a);                \
+        }                                                                                   \
         GATMI_LAUNCH_CHECK(name);                                                           \
     } while (0)
 
@@ -186,7 +336,7 @@ extern "C" int gatmi_ipd_fwd(int64_t B, int32_t N, int32_t F, const float *Z, in
     GATMI_REQUIRE(Z && out, GATMI_EINVAL, "ipd_fwd: null pointer");
     IpdArgs a = {};
     a.N = N; a.F = F; a.Z = Z; a.out = out; a.keep = keep; a.seed = seed; a.activation = activation;
-    GATMI_IPD_LAUNCH(ipd_fwd_kernel, "ipd_fwd");
+    GATMI_IPD_LAUNCH(ipd_fwd_kernel, ipd_fwd_graph_kernel, "ipd_fwd");
     return GATMI_OK;
 }
 
@@ -200,6 +350,6 @@ extern "C" int gatmi_ipd_bwd(int64_t B, int32_t N, int32_t F, const float *dOut,
     IpdArgs a = {};
     a.N = N; a.F = F; a.Z = Z; a.dOut = dOut; a.out_saved = activation == GATMI_ACT_SIGMOID ? out : nullptr;
     a.dZ = dZ; a.keep = keep; a.seed = seed; a.activation = activation;
-    GATMI_IPD_LAUNCH(ipd_bwd_kernel, "ipd_bwd");
+    GATMI_IPD_LAUNCH(ipd_bwd_kernel, ipd_bwd_graph_kernel, "ipd_bwd");
     return GATMI_OK;
 }
