@@ -59,6 +59,18 @@ def main():
             return step
         fused = timed(run(lambda: m(x, A)))
         eager = timed(run(lambda: eager_bnf(x, A, m)))
+        # the same fused step replayed from a HIP graph (the library only enqueues, so it captures whole)
+        step = run(lambda: m(x, A))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        replay = timed(graph.replay)
         z = torch.randn(B, N, F, device=dev, generator=g, requires_grad=True)
         dflat = torch.randn(B * N * N, device=dev, generator=g)
 
@@ -69,7 +81,7 @@ def main():
             return step
         dfused = timed(dec(lambda: InnerProductDecoder(z)))
         deager = timed(dec(lambda: torch.sigmoid(z @ z.transpose(1, 2)).reshape(-1)))
-        res.append({"B": B, "N": N, "F": F, "heads": H, "bnf_step_ms": round(fused, 3), "bnf_eager_torch_ms": round(eager, 3),
+        res.append({"B": B, "N": N, "F": F, "heads": H, "bnf_step_ms": round(fused, 3), "bnf_step_graph_replay_ms": round(replay, 3), "bnf_eager_torch_ms": round(eager, 3),
                     "decoder_ms": round(dfused, 3), "decoder_eager_torch_ms": round(deager, 3),
                     "decoder_GBps": round(B * N * N * 4 * 4 / (dfused * 1e-3) / 1e9, 1)})
     print(json.dumps(res))
