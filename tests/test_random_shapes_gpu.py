@@ -12,11 +12,34 @@ from tests.util import assert_close, layer_params, random_graph
 
 pytestmark = pytest.mark.gpu
 DRAWS = int(os.environ.get("GATMI_SWEEP", "10"))
+KINK = 5e-7       # logits closer to LeakyReLU's kink than fp32 rounding can resolve
 HEAD_SHAPES = [(8, 8), (1, 7), (4, 8), (2, 16), (1, 64), (8, 4), (1, 4), (16, 8), (4, 64), (2, 3), (8, 32), (1, 100)]
 
 
 def _oracle_params(p):
     return {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+
+
+def _close(got, ref, what, **kw):
+    """assert_close, except that a reference that is pure rounding noise (a gradient that is exactly
+    zero in exact arithmetic, e.g. da1 when every row attends to one entry) only asks for ~0."""
+    if ref.size and np.abs(ref).max() < 1e-9:
+        assert np.abs(got).max() < 1e-6, what
+    else:
+        assert_close(got, ref, what=what, **kw)
+
+
+def _min_abs_logit(x, p, pairs):
+    """Smallest |f1_i + f2_j| over the entries `pairs` = (i, j): LeakyReLU has a kink at 0, where an
+    fp32 and an fp64 evaluation may take different slopes and the gradients legitimately differ by
+    0.8 * alpha * (dalpha - c); draws that land within rounding distance of it are redrawn."""
+    F = p["W"].shape[0]
+    H, D = p["a1"].shape
+    wh = (x.reshape(-1, F) @ p["W"].reshape(F, H * D)).reshape(-1, H, D)
+    f1 = (wh * p["a1"]).sum(-1) + p["b1"]
+    f2 = (wh * p["a2"]).sum(-1) + p["b2"]
+    i, j = pairs
+    return float(np.abs(f1[i] + f2[j]).min()) if len(i) else 1.0
 
 
 @pytest.mark.parametrize("seed", range(DRAWS))
@@ -33,10 +56,14 @@ def test_sparse_layer_random_draw(seed):
     chunk = int(rng.choice([4, 32, 256, 2048]))
     activation = str(rng.choice(["elu", "relu", "identity"]))
     reduce = "mean" if activation == "identity" and rng.random() < 0.5 else "concat"
-    res = bool(rng.random() < 0.3) and reduce == "concat"
+    res = bool(rng.random() < 0.3) and reduce == "concat" and F != D      # equal widths: the reference's residual is a no-op (layers.py:31-32)
     dst, src = random_graph(n, deg, seed=seed, hubs=hubs, hub_deg=min(n, 400))
     p = layer_params(F, H, D, seed=seed + 1, res=res)
     x = rng.normal(0, 1, (n, F))
+    for _ in range(50):
+        if _min_abs_logit(x, p, (dst, src)) > KINK:
+            break
+        x = rng.normal(0, 1, (n, F))
     tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
     xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
     what = "seed %d: n=%d F=%d H=%d D=%d deg=%.1f hubs=%d chunk=%d %s/%s res=%s" % (seed, n, F, H, D, deg, hubs, chunk, activation, reduce, res)
@@ -51,9 +78,9 @@ def test_sparse_layer_random_draw(seed):
     dout = rng.normal(0, 1, tuple(out.shape))
     out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
     ref.backward(torch.tensor(dout))
-    assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what=what + " dX")
+    _close(xt.grad.cpu().numpy(), rx.grad.numpy(), what + " dX", atol_scale=5e-6)
     for k in ("W", "a1", "bias") + (("W_res",) if res else ()):
-        assert_close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), atol_scale=5e-6, what=what + " d" + k)
+        _close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), what + " d" + k, atol_scale=5e-6)
 
 
 @pytest.mark.parametrize("seed", range(DRAWS))
@@ -72,6 +99,11 @@ def test_dense_layer_random_draw(seed):
     bm = np.where(adj, rng.normal(0, 1, (B, N, N)) if soft else 0.0, -1e9)
     p = layer_params(F, H, D, seed=seed + 3)
     x = rng.normal(0, 1, (B, N, F))
+    bb, ii, jj = np.nonzero(adj)
+    for _ in range(50):
+        if _min_abs_logit(x, p, (bb * N + ii, bb * N + jj)) > KINK:
+            break
+        x = rng.normal(0, 1, (B, N, F))
     hd = H * ops.padded_width(D)
     paths = ["dense", "lists"] if 32 <= hd <= 64 else (["lists"] if hd > 64 else ["dense"])
     for path in paths:
@@ -87,6 +119,6 @@ def test_dense_layer_random_draw(seed):
         dout = rng.normal(0, 1, tuple(out.shape))
         out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
         ref.backward(torch.tensor(dout))
-        assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what=what + " dX")
+        _close(xt.grad.cpu().numpy(), rx.grad.numpy(), what + " dX", atol_scale=5e-6)
         for k in ("W", "a1", "bias"):
-            assert_close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), atol_scale=5e-6, what=what + " d" + k)
+            _close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), what + " d" + k, atol_scale=5e-6)
