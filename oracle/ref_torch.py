@@ -114,7 +114,7 @@ def bnf_v2e_aggregate(x, net_mat, p):
       agg  = (net1 * att) @ x                                      :179
     Returns agg [B,N,H,F]."""
     B, n, Fin = x.shape
-    H, Dz = p["a1"].shape
+    _, H, Dz = p["W"].shape                 # a1 / a2 may also come as one leaf per node, [B,N,H,Dz]
     z = (x @ p["W"].reshape(Fin, H * Dz)).reshape(B, n, H, Dz)
     f1 = (z * p["a1"]).sum(-1) + p["b1"]                       # [B,N,H]
     f2 = (z * p["a2"]).sum(-1) + p["b2"]

@@ -122,3 +122,59 @@ def test_dense_layer_random_draw(seed):
         _close(xt.grad.cpu().numpy(), rx.grad.numpy(), what + " dX", atol_scale=5e-6)
         for k in ("W", "a1", "bias"):
             _close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), what + " d" + k, atol_scale=5e-6)
+
+
+@pytest.mark.parametrize("seed", range(max(1, DRAWS // 2)))
+def test_decoder_and_bnf_random_draw(seed):
+    from gat_amd import ops
+    from gat_amd.layers import BNFAttention
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3000 + seed)
+    # inner-product decoder
+    B, N, F = int(rng.integers(1, 7)), int(rng.integers(1, 320)), int(rng.integers(1, 129))
+    activation = str(rng.choice(["sigmoid", "identity"]))
+    z = rng.normal(0, 0.5, (B, N, F))
+    zt = torch.tensor(z, dtype=torch.float32, device=dev, requires_grad=True)
+    what = "seed %d: decoder B=%d N=%d F=%d %s" % (seed, B, N, F, activation)
+    out = ops.inner_product_decoder(zt, activation).reshape(-1)
+    rz = torch.tensor(z, dtype=torch.float64, requires_grad=True)
+    ref = ref_torch.inner_product_decoder(rz, activation)
+    assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), what=what + " forward")
+    dout = rng.normal(0, 1, (B * N * N,))
+    out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
+    ref.backward(torch.tensor(dout))
+    _close(zt.grad.cpu().numpy(), rz.grad.numpy(), what + " dZ", atol_scale=5e-6)
+    # brain-network attention step
+    B, N, F = int(rng.integers(1, 4)), int(rng.integers(2, 280)), int(rng.integers(1, 65))
+    H, Dz = int(rng.integers(1, 5)), int(rng.choice([8, 16, 64]))
+    x = rng.normal(0, 1, (B, N, F))
+    A = rng.random((B, N, N)) * (rng.random((B, N, N)) < rng.choice([0.05, 0.3, 1.0]))
+    p = {"W": rng.normal(0, 0.4, (F, H, Dz)), "a1": rng.normal(0, 0.4, (H, Dz)), "a2": rng.normal(0, 0.4, (H, Dz)),
+         "b1": rng.normal(0, 0.1, H), "b2": rng.normal(0, 0.1, H), "m1": 1 + rng.normal(0, 0.2, H), "m2": 1 + rng.normal(0, 0.2, H)}
+    mod = BNFAttention(F, H, Dz, device=dev)
+    with torch.no_grad():
+        for k, v in p.items():
+            getattr(mod, k).copy_(torch.tensor(v, dtype=torch.float32))
+    xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
+    At = torch.tensor(A, dtype=torch.float32, device=dev, requires_grad=True)
+    what = "seed %d: bnf B=%d N=%d F=%d H=%d Dz=%d" % (seed, B, N, F, H, Dz)
+    out = mod(xt, At)
+    rp = _oracle_params(p)
+    rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    rA = torch.tensor(A, dtype=torch.float64, requires_grad=True)
+    ref = ref_torch.bnf_v2e_aggregate(rx, rA, rp)
+    assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), what=what + " forward")
+    dout = rng.normal(0, 1, tuple(ref.shape))
+    out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
+    ref.backward(torch.tensor(dout))
+    _close(xt.grad.cpu().numpy(), rx.grad.numpy(), what + " dX", atol_scale=5e-6)
+    _close(At.grad.cpu().numpy(), rA.grad.numpy(), what + " dA", atol_scale=5e-6)
+    # The projection only feeds the logit halves here, and the gradient of a logit half comes from the
+    # identity df1 = (1-slope)(<G,pos> - c q), a difference of two numbers of the size of |G||out| (tens,
+    # with 64 features) that is often a hundred times smaller than either: its fp32 error is absolute,
+    # ~1e-7 of those numbers per node, and dW / da1 / dm inherit it.  Band: 1e-4 relative + 3e-5 absolute
+    # for inputs of unit scale.
+    for k in ("W", "a1", "m1", "m2"):
+        got, want = getattr(mod, k).grad.cpu().numpy().astype(np.float64), rp[k].grad.numpy()
+        tol = 1e-4 * np.abs(want) + 1e-4 * np.abs(want).max() + 3e-5
+        assert (np.abs(got - want) <= tol).all(), "%s d%s: worst %.3g of the band" % (what, k, (np.abs(got - want) / tol).max())
