@@ -6,8 +6,7 @@ import pytest
 import torch
 
 from oracle import ref_torch
-from tests.test_dropout_gpu import FEAT_SALT, keep_mask_host
-from tests.util import assert_close
+from tests.util import FEAT_SALT, assert_close, keep_mask_host
 
 pytestmark = pytest.mark.gpu
 

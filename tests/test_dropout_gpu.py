@@ -9,23 +9,9 @@ import pytest
 import torch
 
 from oracle import ref_numpy, ref_torch
-from tests.util import assert_close, layer_params, random_graph
+from tests.util import FEAT_SALT, assert_close, keep_mask_host, layer_params, random_graph
 
 pytestmark = pytest.mark.gpu
-
-FEAT_SALT = 0x5DEECE66D
-
-
-def keep_mask_host(seed, idx, keep):
-    """Host twin of keep_mask in gat_amd/csrc/device_common.h (splitmix64 finaliser, top 24 bits)."""
-    with np.errstate(over="ignore"):
-        z = idx.astype(np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    r = (z >> np.uint64(40)).astype(np.float32)
-    return (r * np.float32(1.0 / 16777216.0)) < np.float32(keep)
-
 
 @pytest.mark.parametrize("H,D,coef_drop,in_drop", [(8, 8, 0.6, 0.6), (1, 7, 0.3, 0.0), (4, 8, 0.0, 0.5)])
 def test_masks_replay_in_forward_and_backward(H, D, coef_drop, in_drop):

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import ref_torch
-from tests.util import assert_close, layer_params, random_graph
+from tests.util import assert_close, dense_dropout_masks, layer_params, random_graph, sparse_dropout_masks
 
 pytestmark = pytest.mark.gpu
 DRAWS = int(os.environ.get("GATMI_SWEEP", "10"))
@@ -66,14 +66,20 @@ def test_sparse_layer_random_draw(seed):
         x = rng.normal(0, 1, (n, F))
     tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
     xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
-    what = "seed %d: n=%d F=%d H=%d D=%d deg=%.1f hubs=%d chunk=%d %s/%s res=%s" % (seed, n, F, H, D, deg, hubs, chunk, activation, reduce, res)
+    coef_drop, in_drop = (float(rng.choice([0.0, 0.3, 0.6])), float(rng.choice([0.0, 0.5]))) if rng.random() < 0.35 else (0.0, 0.0)
+    what = "seed %d: n=%d F=%d H=%d D=%d deg=%.1f hubs=%d chunk=%d %s/%s res=%s drop=%.1f/%.1f" % (
+        seed, n, F, H, D, deg, hubs, chunk, activation, reduce, res, coef_drop, in_drop)
+    cfg = ops.make_cfg(H, D, activation, reduce, coef_drop=coef_drop, in_drop=in_drop, training=True, seed=4242 + seed)
     out = ops.sparse_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"],
-                               CSRGraph.from_coo(dst, src, n, dev, chunk=chunk), ops.make_cfg(H, D, activation, reduce),
-                               tp.get("W_res"), tp.get("b_res"))
+                               CSRGraph.from_coo(dst, src, n, dev, chunk=chunk), cfg, tp.get("W_res"), tp.get("b_res"))
     rowptr, col = ref_numpy.coo_to_csr(np.stack([dst, src], 1), n)
+    coef_mask, ft_mask = sparse_dropout_masks(4242 + seed, len(col), n, H, D, cfg.dp, coef_drop, in_drop)
     rp = _oracle_params(p)
     rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
-    ref = ref_torch.layer_csr(rx, rp, torch.tensor(rowptr), torch.tensor(col), activation, reduce, residual=res)
+    ref = ref_torch.layer_csr(rx, rp, torch.tensor(rowptr), torch.tensor(col), activation, reduce, residual=res,
+                              coef_mask=None if coef_mask is None else torch.tensor(coef_mask),
+                              ft_mask=None if ft_mask is None else torch.tensor(ft_mask),
+                              coef_keep=1.0 - coef_drop, ft_keep=1.0 - in_drop)
     assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), what=what + " forward")
     dout = rng.normal(0, 1, tuple(out.shape))
     out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
@@ -106,15 +112,22 @@ def test_dense_layer_random_draw(seed):
         x = rng.normal(0, 1, (B, N, F))
     hd = H * ops.padded_width(D)
     paths = ["dense", "lists"] if 32 <= hd <= 64 else (["lists"] if hd > 64 else ["dense"])
+    coef_drop, in_drop = (float(rng.choice([0.0, 0.3, 0.6])), float(rng.choice([0.0, 0.5]))) if (rng.random() < 0.35 and N <= 150) else (0.0, 0.0)
+    coef_mask, ft_mask = dense_dropout_masks(777 + seed, B, N, H, D, ops.padded_width(D), coef_drop, in_drop)
     for path in paths:
         tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
         xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
-        what = "seed %d: B=%d N=%d F=%d H=%d D=%d density=%.2f soft=%s %s %s" % (seed, B, N, F, H, D, density, soft, activation, path)
+        what = "seed %d: B=%d N=%d F=%d H=%d D=%d density=%.2f soft=%s %s %s drop=%.1f/%.1f" % (
+            seed, B, N, F, H, D, density, soft, activation, path, coef_drop, in_drop)
+        cfg = ops.make_cfg(H, D, activation, mask_path=path, coef_drop=coef_drop, in_drop=in_drop, training=True, seed=777 + seed)
         out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"],
-                                  torch.tensor(bm, dtype=torch.float32, device=dev), ops.make_cfg(H, D, activation, mask_path=path))
+                                  torch.tensor(bm, dtype=torch.float32, device=dev), cfg)
         rp = _oracle_params(p)
         rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
-        ref = ref_torch.layer_dense(rx, rp, torch.tensor(bm), activation, "concat")
+        ref = ref_torch.layer_dense(rx, rp, torch.tensor(bm), activation, "concat",
+                                    coef_mask=None if coef_mask is None else torch.tensor(coef_mask),
+                                    ft_mask=None if ft_mask is None else torch.tensor(ft_mask),
+                                    coef_keep=1.0 - coef_drop, ft_keep=1.0 - in_drop)
         assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), what=what + " forward")
         dout = rng.normal(0, 1, tuple(out.shape))
         out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))

@@ -59,3 +59,47 @@ def assert_close(got, ref, rtol=1e-5, atol_scale=2e-6, what=""):
         k = np.unravel_index(np.argmax(err / tol), err.shape)
         raise AssertionError("%s: %d/%d elements out of tolerance; worst at %s got %.9g ref %.9g (err %.3g, tol %.3g, scale %.3g)"
                              % (what, bad.sum(), bad.size, k, got[k], ref[k], err[k], tol[k], scale))
+
+
+# ---- host twins of the in-kernel dropout masks ---------------------------------------------------
+FEAT_SALT = 0x5DEECE66D
+
+
+def keep_mask_host(seed, idx, keep):
+    """Host twin of keep_mask in gat_amd/csrc/device_common.h (splitmix64 finaliser, top 24 bits)."""
+    with np.errstate(over="ignore"):
+        z = idx.astype(np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    r = (z >> np.uint64(40)).astype(np.float32)
+    return (r * np.float32(1.0 / 16777216.0)) < np.float32(keep)
+
+
+def sparse_dropout_masks(seed, n_entries, n, H, D, dp, coef_drop, in_drop):
+    """Masks the CSR kernels draw: coefficients keyed on (CSR position, head) -> [E,H]; projected
+    features keyed on (source, padded column) -> [n,H,D].  None where the rate is 0."""
+    coef = ft = None
+    if coef_drop > 0:
+        idx = np.arange(n_entries, dtype=np.uint64)[:, None] * np.uint64(H) + np.arange(H, dtype=np.uint64)[None, :]
+        coef = keep_mask_host(seed, idx, 1.0 - coef_drop).astype(np.float64)
+    if in_drop > 0:
+        cols = (np.arange(H)[:, None] * dp + np.arange(D)[None, :]).astype(np.uint64)
+        idx = np.arange(n, dtype=np.uint64)[:, None, None] * np.uint64(H * dp) + cols[None]
+        ft = keep_mask_host(seed ^ FEAT_SALT, idx, 1.0 - in_drop).astype(np.float64)
+    return coef, ft
+
+
+def dense_dropout_masks(seed, B, N, H, D, dp, coef_drop, in_drop):
+    """Masks the dense kernels draw: coefficients keyed on (graph, i, j, head) -> [B,H,N,N];
+    projected features keyed on (graph*N + node, padded column) -> [B,N,H,D]."""
+    coef = ft = None
+    if coef_drop > 0:
+        b, i, j, h = np.meshgrid(np.arange(B), np.arange(N), np.arange(N), np.arange(H), indexing="ij")
+        idx = (((b * N + i) * N + j) * H + h).astype(np.uint64)
+        coef = keep_mask_host(seed, idx, 1.0 - coef_drop).astype(np.float64).transpose(0, 3, 1, 2)
+    if in_drop > 0:
+        cols = (np.arange(H)[:, None] * dp + np.arange(D)[None, :]).astype(np.uint64)
+        idx = np.arange(B * N, dtype=np.uint64)[:, None, None] * np.uint64(H * dp) + cols[None]
+        ft = keep_mask_host(seed ^ FEAT_SALT, idx, 1.0 - in_drop).astype(np.float64).reshape(B, N, H, D)
+    return coef, ft
