@@ -82,6 +82,36 @@ def _worker(rank, world, port, q):
         gdist.allreduce_grads(list(b_.values()))
         assert_close(o16.detach().cpu().numpy(), ref.detach().cpu().numpy()[lo:hi], rtol=2e-2, atol_scale=2e-2, what="bf16 out")
         assert_close(b_["W"].grad.cpu().numpy(), tp["W"].grad.cpu().numpy(), rtol=2e-2, atol_scale=2e-2, what="bf16 dW")
+        # other shapes, a third of the rows on one rank, the identity / mean output layer
+        for (n2, F2, H2, D2, act2, red2, seed2) in ((333, 7, 1, 7, "identity", "mean", 1), (1000, 33, 4, 16, "relu", "concat", 2), (64, 5, 2, 4, "elu", "concat", 3)):
+            dst2, src2 = random_graph(n2, 4.0, seed2, hubs=1, hub_deg=min(n2, 300))
+            rowptr2, col2, _ = graph.csr_from_coo_host(n2, dst2, src2)
+            part2 = np.array([0, n2 // 3, n2], dtype=np.int64) if seed2 == 1 else gdist.partition_rows(n2, world, rowptr2, balance=seed2 % 2)
+            lo2, hi2 = int(part2[rank]), int(part2[rank + 1])
+            p2 = layer_params(F2, H2, D2, seed=seed2)
+            x2 = np.random.default_rng(seed2).normal(0, 1, (n2, F2)).astype(np.float32)
+            cfg2 = ops.make_cfg(H2, D2, act2, red2)
+            mk = lambda: {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p2.items()}
+            t2 = mk()
+            xs2 = torch.tensor(x2, device=dev, requires_grad=True)
+            ref2 = ops.sparse_gat_layer(xs2, t2["W"], t2["a1"], t2["a2"], t2["b1"], t2["b2"], t2["bias"],
+                                        CSRGraph.from_coo(dst2, src2, n2, dev, chunk=32), cfg2)
+            do2 = np.random.default_rng(seed2 + 9).normal(0, 1, tuple(ref2.shape)).astype(np.float32)
+            ref2.backward(torch.tensor(do2, device=dev))
+            pg2 = gdist.PartitionedGraph.from_global_csr(rowptr2, col2, part2, rank, world, dev, chunk=32)
+            for mode in ("exchange", "replicate"):
+                d2 = mk()
+                xd2 = torch.tensor(x2[lo2:hi2], device=dev, requires_grad=(mode == "exchange"))
+                xin = xd2 if mode == "exchange" else pg2.replicate_rows(xd2)
+                o2 = gdist.dist_sparse_gat_layer(xin, d2["W"], d2["a1"], d2["a2"], d2["b1"], d2["b2"], d2["bias"], pg2, cfg2, halo=mode)
+                o2.backward(torch.tensor(do2[lo2:hi2], device=dev))
+                gdist.allreduce_grads(list(d2.values()))
+                tag = "n=%d %s" % (n2, mode)
+                assert_close(o2.detach().cpu().numpy(), ref2.detach().cpu().numpy()[lo2:hi2], rtol=2e-6, atol_scale=1e-6, what=tag + " out")
+                if mode == "exchange":
+                    assert_close(xd2.grad.cpu().numpy(), xs2.grad.cpu().numpy()[lo2:hi2], rtol=1e-5, atol_scale=2e-6, what=tag + " dX")
+                for k in p2:
+                    assert_close(d2[k].grad.cpu().numpy(), t2[k].grad.cpu().numpy(), rtol=1e-5, atol_scale=5e-6, what=tag + " d" + k)
         # the device-side planner gives the same shard
         e0, e1 = int(rowptr[lo]), int(rowptr[hi])
         dl = torch.tensor(np.repeat(np.arange(lo, hi), np.diff(rowptr[lo:hi + 1])), dtype=torch.int64, device=dev)
