@@ -55,17 +55,23 @@ def main():
     ap.add_argument("--epochs", type=int, default=200)
     ap.add_argument("--patience", type=int, default=100)
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--sparse-features", action="store_true",
+                    help="feed the sparse tuple of preprocess_features (stored entries only) instead of the dense matrix")
     args = ap.parse_args()
     from gat_amd import CSRGraph, layers, preprocess
     from gat_amd.models import SpGAT
 
     dev = torch.device("cuda:0")
     adj, feats, onehot, (m_train, m_val, m_test) = synthetic_cora()
-    features, _ = preprocess.preprocess_features(feats)                    # execute_cora_sparse.py:37
+    features, features_tuple = preprocess.preprocess_features(feats)       # execute_cora_sparse.py:37
     biases = preprocess.preprocess_adj_bias(adj)                           # execute_cora_sparse.py:58
     graph = CSRGraph.from_reference_triple(biases, dev)                    # built once, reused every step
     n, f = features.shape
-    x = torch.tensor(np.asarray(features)[None], dtype=torch.float32, device=dev)
+    if args.sparse_features:
+        from gat_amd.features import SparseFeatures
+        x = SparseFeatures.from_tuple(features_tuple, dev)                 # 1.3 % of the entries of the dense matrix
+    else:
+        x = torch.tensor(np.asarray(features)[None], dtype=torch.float32, device=dev)
     y = torch.tensor(onehot, dtype=torch.float32, device=dev)
     masks = {k: torch.tensor(v, device=dev) for k, v in (("train", m_train), ("val", m_val), ("test", m_test))}
 

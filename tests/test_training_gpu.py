@@ -10,9 +10,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cora_like_training_learns():
+@pytest.mark.parametrize("extra", [[], ["--sparse-features"]])
+def test_cora_like_training_learns(extra):
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import train_cora_like
-    sys.argv = ["train_cora_like.py", "--epochs", "100", "--quiet"]
+    sys.argv = ["train_cora_like.py", "--epochs", "100", "--quiet"] + extra
     acc = train_cora_like.main()
     assert acc > 0.6, "test accuracy %.3f after 100 epochs (chance is 0.14)" % acc
