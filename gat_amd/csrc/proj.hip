@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const int64_t *rowptr, c
 // dW = X^T . dWh, reduced over nodes.  Block (bx, by): node chunks bx, bx+gridDim.x, ...;
 // feature rows [by*16*MT, +16*MT).  Each wave keeps an [16*MT x 16*NT] partial in registers.
 // ------------------------------------------------------------------------------------------
-constexpr int kRedBlocks = 512;
+constexpr int kRedBlocks = 768;
 constexpr int kNodeChunk = 64;
 
 template <int MT, int NT>
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void xt_gemm_kernel(const float *X, int64_t n,
 // Block (bx, by, bz): node chunks bx, bx+gridDim.x, ...; features [128*by, +64*FS); columns [64*bz, +64).
 // ------------------------------------------------------------------------------------------
 template <int FS>
-__global__ __launch_bounds__(256, 2) void xt_gemm_lines_kernel(const float *X, int64_t n, int F, int64_t ldx,
+__global__ __launch_bounds__(256, 3) void xt_gemm_lines_kernel(const float *X, int64_t n, int F, int64_t ldx,
                                                              const float *dY, int hd, float *ws) {
     __shared__ float red[64 * FS * 65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
