@@ -44,3 +44,34 @@ def test_decoder_rejects_wide_embeddings():
     from gat_amd import ops
     with pytest.raises(ValueError):
         ops.inner_product_decoder(torch.zeros(1, 4, 129, device="cuda:0"))
+
+
+def test_decoder_replays_from_a_hip_graph():
+    """The whole-graph kernels raise their dynamic-LDS limit before launching (more than 48 KB for
+    264 nodes x 64 features); that call, and the launches, must be capturable."""
+    from gat_amd.layers import InnerProductDecoder
+    dev = torch.device("cuda:0")
+    B, N, F = 3, 264, 64
+    z = torch.randn(B, N, F, device=dev, requires_grad=True)
+    d = torch.randn(B * N * N, device=dev)
+
+    def step():
+        z.grad = None
+        out = InnerProductDecoder(z)
+        out.backward(d)
+        return out
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            eager = step().detach().clone()
+    torch.cuda.current_stream().wait_stream(side)
+    eager_grad = z.grad.detach().clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        captured = step()
+    z.grad.zero_()
+    captured.detach().zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured.detach(), eager) and torch.equal(z.grad, eager_grad)
