@@ -20,7 +20,7 @@ from . import layers
 
 
 class BaseGAttN:
-    """Loss / metric / optimiser helpers of models/base_gattn.py used on the Cora path."""
+    """Loss / metric / optimiser helpers of models/base_gattn.py."""
 
     @staticmethod
     def loss(logits, labels):
@@ -45,6 +45,77 @@ class BaseGAttN:
     def accuracy(preds, labels):
         """base_gattn.py:90-93."""
         return (preds.argmax(1) == labels.argmax(1)).to(torch.float32).mean()
+
+    # ---- losses and metrics of the brain-network drivers (plain tensor arithmetic) -------------
+    @staticmethod
+    def _xent(logits, labels):
+        return -(labels * torch.log_softmax(logits, dim=-1)).sum(-1).mean(0)
+
+    @staticmethod
+    def bi_loss(logits, labels, fmri_net, recon_net_fmri, DTI_net, recon_net_DTI, recon_lr_weight):
+        """base_gattn.py:18-29: cross-entropy + weight * (MSE(fmri) + 0.1 * MSE(DTI))."""
+        rec_f = ((fmri_net - recon_net_fmri) ** 2).mean()
+        rec_d = ((DTI_net - recon_net_DTI) ** 2).mean()
+        return BaseGAttN._xent(logits, labels) + recon_lr_weight * (rec_f + 0.1 * rec_d)
+
+    @staticmethod
+    def AE_classify_loss(logits, labels, fmri_net, recon_net_fmri, DTI_net, reconstruct_DTI, recon_lr_weight):
+        """base_gattn.py:31-41: the DTI reconstruction error is weighted by |DTI_net|, the fMRI one is plain."""
+        rec_d = (((DTI_net - reconstruct_DTI) ** 2) * DTI_net.abs()).mean()
+        rec_f = ((fmri_net - recon_net_fmri) ** 2).mean()
+        return BaseGAttN._xent(logits, labels) + recon_lr_weight * (rec_f + 0.1 * rec_d)
+
+    @staticmethod
+    def AE_regression_loss(logits, labels, fmri_net, recon_net_fmri, DTI_net, reconstruct_DTI, recon_lr_weight):
+        """base_gattn.py:43-58: MSE on the target + weight * (|.|-weighted reconstruction errors)."""
+        rec_d = (((DTI_net - reconstruct_DTI) ** 2) * DTI_net.abs()).mean()
+        rec_f = (((fmri_net - recon_net_fmri) ** 2) * fmri_net.abs()).mean()
+        return ((labels - logits) ** 2).mean() + recon_lr_weight * (rec_f + rec_d)
+
+    @staticmethod
+    def syn_loss(logits, labels, fmri_net, recon_net_fmri, recon_lr_weight):
+        """base_gattn.py:61-72."""
+        return ((labels - logits) ** 2).mean() + recon_lr_weight * ((fmri_net - recon_net_fmri) ** 2).mean()
+
+    @staticmethod
+    def syn_accuracy(preds, labels):
+        """base_gattn.py:95-107: Pearson correlation of predictions and targets (epsilon 1e-7 as Keras')."""
+        p, l = preds.squeeze(), labels.squeeze()
+        pc, lc = p - p.mean(), l - l.mean()
+        return (pc * lc).sum() / (torch.sqrt((pc * pc).sum() * (lc * lc).sum()) + 1e-7)
+
+    @staticmethod
+    def preshape(logits, labels, nb_classes):
+        """base_gattn.py:109-114."""
+        return logits.reshape(-1, nb_classes), labels.reshape(-1)
+
+    @staticmethod
+    def confmat(logits, labels):
+        """base_gattn.py:116-118: rows = true class, columns = predicted class."""
+        preds = logits.argmax(1)
+        k = int(max(int(labels.max()), int(preds.max()))) + 1
+        return torch.bincount(labels.long() * k + preds, minlength=k * k).reshape(k, k)
+
+    @staticmethod
+    def MSE(preds, labels):
+        """base_gattn.py:121-124."""
+        return ((labels.squeeze() - preds.squeeze()) ** 2).mean()
+
+    @staticmethod
+    def MAE(preds, labels):
+        """base_gattn.py:126-129."""
+        return (labels.squeeze() - preds.squeeze()).abs().mean()
+
+    @staticmethod
+    def micro_f1(logits, labels):
+        """base_gattn.py:167-188 (two classes: the arg-max index doubles as the 0/1 prediction).
+        Returns (f-measure, precision, recall)."""
+        predicted, lab = logits.argmax(1), labels.argmax(1)
+        tp = ((predicted * lab) != 0).sum().double()
+        fp = ((predicted * (lab - 1)) != 0).sum().double()
+        fn = (((predicted - 1) * lab) != 0).sum().double()
+        precision, recall = tp / (tp + fp), tp / (tp + fn)
+        return (2 * precision * recall / (precision + recall)).float(), precision, recall
 
     @staticmethod
     def l2_penalty(parameters, l2_coef):

@@ -184,3 +184,30 @@ def test_two_layer_composition():
     t = ref_torch.inference_csr(torch.tensor(x), [{k: torch.tensor(v) for k, v in l.items()} for l in (l0, l1)],
                                 torch.tensor(rowptr), torch.tensor(col)).numpy()
     np.testing.assert_allclose(t, out, rtol=1e-11, atol=1e-12)
+
+
+def test_base_gattn_losses_and_metrics():
+    """The plain-arithmetic helpers of models/base_gattn.py against hand-computed values."""
+    import torch
+    from gat_amd.models import BaseGAttN as M
+    logits = torch.tensor([[2.0, 0.0], [0.0, 1.0], [3.0, 1.0], [0.5, 0.7]])
+    labels = torch.tensor([[1.0, 0.0], [0.0, 1.0], [0.0, 1.0], [1.0, 0.0]])
+    ce = -(labels * torch.log_softmax(logits, -1)).sum(-1).mean()
+    assert torch.allclose(M.loss(logits, labels), ce)
+    a, ra = torch.tensor([[1.0, -2.0]]), torch.tensor([[0.5, -1.0]])
+    d, rd = torch.tensor([[2.0, 0.0]]), torch.tensor([[1.0, 1.0]])
+    assert torch.allclose(M.bi_loss(logits, labels, a, ra, d, rd, 0.5), ce + 0.5 * (0.625 + 0.1 * 1.0))
+    assert torch.allclose(M.AE_classify_loss(logits, labels, a, ra, d, rd, 0.5), ce + 0.5 * (0.625 + 0.1 * 1.0))      # |d| weights: (1*2 + 1*0)/2 = 1
+    assert torch.allclose(M.AE_regression_loss(logits, labels, a, ra, d, rd, 2.0),
+                          ((labels - logits) ** 2).mean() + 2.0 * ((0.25 * 1 + 1.0 * 2) / 2 + 1.0))
+    assert torch.allclose(M.syn_loss(logits, labels, a, ra, 2.0), ((labels - logits) ** 2).mean() + 2.0 * 0.625)
+    x = torch.tensor([1.0, 2.0, 3.0, 4.0])
+    assert abs(float(M.syn_accuracy(x, 2 * x + 1)) - 1.0) < 1e-5 and abs(float(M.syn_accuracy(x, -x)) + 1.0) < 1e-5
+    assert float(M.accuracy(logits, labels)) == 0.5
+    assert M.confmat(logits, labels.argmax(1)).tolist() == [[1, 1], [1, 1]]
+    f, p, r = M.micro_f1(logits, labels)
+    assert float(p) == 0.5 and float(r) == 0.5 and abs(float(f) - 0.5) < 1e-6
+    assert float(M.MSE(torch.tensor([[1.0], [3.0]]), torch.tensor([0.0, 1.0]))) == 2.5
+    assert float(M.MAE(torch.tensor([[1.0], [3.0]]), torch.tensor([0.0, 1.0]))) == 1.5
+    lg, lb = M.preshape(torch.zeros(2, 3, 4), torch.zeros(2, 3), 4)
+    assert tuple(lg.shape) == (6, 4) and tuple(lb.shape) == (6,)
