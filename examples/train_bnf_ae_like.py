@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""The brain-network auto-encoder the reference's BNF_AE.py selects (GAT_AE_BNF_V2, models/gat.py:188-243)
+trained with its loss (AE_classify_loss, models/base_gattn.py:31-41) and Adam + L2
+(base_gattn.py:75-88; BNF_AE.py:17-30 uses lr 0.001, l2 0.001, batch 50) on SYNTHETIC connectomes:
+the HCP data the reference reads is restricted and absent.  Two classes of 90-node weighted
+graphs differ in the strength of one block of connections; the node feature is the node's strength.
+
+    python examples/train_bnf_ae_like.py --steps 60
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def synthetic_connectomes(batch, nodes, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    y = torch.randint(0, 2, (batch,), device=device, generator=g)
+    w = torch.rand(batch, nodes, nodes, device=device, generator=g) * (torch.rand(batch, nodes, nodes, device=device, generator=g) < 0.3)
+    k = nodes // 3
+    w[:, :k, :k] = w[:, :k, :k] * (1.0 + 2.0 * y[:, None, None])      # class 1: a three times stronger block
+    w = (w + w.transpose(1, 2)) / 2
+    x = w.sum(-1, keepdim=True) / nodes
+    return x, w, torch.nn.functional.one_hot(y, 2).float()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--batch", type=int, default=50)
+    ap.add_argument("--nodes", type=int, default=90)
+    ap.add_argument("--quiet", action="store_true")
+    args = ap.parse_args()
+    from gat_amd.models import BaseGAttN, GAT_AE_BNF_V2
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = GAT_AE_BNF_V2(1, args.nodes, 2, nb_CAM=64, hid_units=[16, 8, 8], n_heads=[2, 2, 2], device=dev)
+    opt, l2 = BaseGAttN.training(model.parameters(), lr=0.001, l2_coef=0.001)
+    xv, wv, yv = synthetic_connectomes(200, args.nodes, dev, 1)
+    first = last = None
+    t0 = time.time()
+    for step in range(args.steps):
+        x, w, y = synthetic_connectomes(args.batch, args.nodes, dev, 100 + step)
+        opt.zero_grad(set_to_none=True)
+        digits, rec_a, rec_b, _, _ = model(x, w, training=True)
+        target = (w > 0).float()                                            # reconstruct which pairs are connected
+        loss = BaseGAttN.AE_classify_loss(digits, y, target, rec_a, target, rec_b, 1.0) + l2()
+        loss.backward()
+        opt.step()
+        last = loss.item()
+        first = last if first is None else first
+        if not args.quiet and step % 10 == 0:
+            print("step %3d  loss %.4f" % (step, last))
+    with torch.no_grad():
+        acc = float(BaseGAttN.accuracy(model(xv, wv, training=False)[0], yv))
+    print("steps %d  %.2f s  loss %.4f -> %.4f  held-out accuracy %.3f" % (args.steps, time.time() - t0, first, last, acc))
+    return first, last, acc
+
+
+if __name__ == "__main__":
+    main()

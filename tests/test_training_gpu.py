@@ -17,3 +17,13 @@ def test_cora_like_training_learns(extra):
     sys.argv = ["train_cora_like.py", "--epochs", "100", "--quiet"] + extra
     acc = train_cora_like.main()
     assert acc > 0.6, "test accuracy %.3f after 100 epochs (chance is 0.14)" % acc
+
+
+def test_brain_network_autoencoder_learns():
+    """GAT_AE_BNF_V2 + AE_classify_loss + Adam (models/gat.py:188-243, base_gattn.py:31-41,75-88) on
+    synthetic two-class connectomes: the loss falls and held-out graphs are classified."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import train_bnf_ae_like
+    sys.argv = ["train_bnf_ae_like.py", "--steps", "80", "--quiet"]
+    first, last, acc = train_bnf_ae_like.main()
+    assert last < 0.8 * first and acc > 0.8, (first, last, acc)
