@@ -39,6 +39,7 @@ def eager_bnf(x, A, m):
 
 
 def main():
+    from gat_amd import graphs
     from gat_amd.layers import BNFAttention, InnerProductDecoder
     dev = torch.device("cuda:0")
     res = []
@@ -60,17 +61,8 @@ def main():
         fused = timed(run(lambda: m(x, A)))
         eager = timed(run(lambda: eager_bnf(x, A, m)))
         # the same fused step replayed from a HIP graph (the library only enqueues, so it captures whole)
-        step = run(lambda: m(x, A))
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
-        replay = timed(graph.replay)
+        replay_fn, _ = graphs.capture(run(lambda: m(x, A)))
+        replay = timed(replay_fn)
         z = torch.randn(B, N, F, device=dev, generator=g, requires_grad=True)
         dflat = torch.randn(B * N * N, device=dev, generator=g)
 

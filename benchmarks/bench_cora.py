@@ -29,7 +29,7 @@ def timed(fn, iters, sync):
 
 
 def main():
-    from gat_amd import CSRGraph, layers, preprocess
+    from gat_amd import CSRGraph, graphs, layers, preprocess
     from gat_amd.features import SparseFeatures
     from gat_amd.models import GAT, SpGAT
     dev = torch.device("cuda:0")
@@ -57,16 +57,8 @@ def main():
             out.sum().backward()
         res[name + "_gpu_ms"] = round(timed(step, 20, torch.cuda.synchronize), 4)
         # the same step captured once into a HIP graph and replayed (the eager step is launch-bound)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        graph_obj = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph_obj):
-            step()
-        res[name + "_gpu_graph_ms"] = round(timed(graph_obj.replay, 50, torch.cuda.synchronize), 4)
+        replay, _ = graphs.capture(step)
+        res[name + "_gpu_graph_ms"] = round(timed(replay, 50, torch.cuda.synchronize), 4)
     print(json.dumps(res))
 
 

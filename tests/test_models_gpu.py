@@ -182,19 +182,13 @@ def test_training_step_replays_from_a_hip_graph():
         static_out.copy_(out.detach())
     step()
     eager = (static_out.clone(), m.W.grad.clone(), m.a1.grad.clone())
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        step()
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        step()
+    from gat_amd import graphs
+    replay, _ = graphs.capture(step, warmup=1)
     x.copy_(torch.randn(n, F, device=dev))        # new input, then back: replays must track the buffers
-    graph.replay()
+    replay()
     assert not torch.equal(static_out, eager[0])
     x.copy_(torch.randn(n, F, device=dev, generator=torch.Generator(device=dev).manual_seed(0)))
-    graph.replay()
+    replay()
     a = static_out.clone()
     step()
     torch.cuda.synchronize()
