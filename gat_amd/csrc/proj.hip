@@ -42,13 +42,22 @@ struct GemmArgs {
 };
 
 // C[n, Nc] = A[n, K] . B[K, Nc]; B small.  VEC: A rows are 16-byte aligned and K % 4 == 0.
-template <bool VEC>
+// SPLITK = false: a block owns 128 rows, each wave 32 of them, and walks K in slabs of 64.
+// SPLITK = true (few rows, long K: Cora's 2708 x 1433 features): a block owns 32 rows, its four
+// waves take a quarter of every 128-deep slab each and their partial tiles are added in wave
+// order through LDS, so four times as many blocks run and each walks a quarter of K.
+template <bool VEC, bool SPLITK>
 __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float lds[kTileRows * kLdB];  // B slab (64 rows), later the C tile (128 rows)
+    constexpr int ROWS = SPLITK ? 32 : kTileRows;      // rows of C per block
+    constexpr int SLAB = SPLITK ? 128 : kChunkK;       // K extent staged per step
+    constexpr int S = SPLITK ? 2 : 4;                  // 16-deep k-steps a wave takes from a slab
+    __shared__ __attribute__((aligned(16))) float lds[kTileRows * kLdB];  // B slab, later the C tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * kTileRows;
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
     const int col0 = blockIdx.y * kTileCols;
+    const int wrow = SPLITK ? 0 : wave * 32;           // first row of this wave inside the block
+    const int wk = SPLITK ? wave * 32 : 0;             // first slab row of this wave
 
     f32x4 acc[2][4];
 #pragma unroll
@@ -60,34 +69,34 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
     bool rok[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        arow[mt] = row0 + wave * 32 + mt * 16 + m;
+        arow[mt] = row0 + wrow + mt * 16 + m;
         rok[mt] = arow[mt] < g.n;
     }
 
-    for (int kc = 0; kc < g.K; kc += kChunkK) {
+    for (int kc = 0; kc < g.K; kc += SLAB) {
         __syncthreads();
-        // stage B[kc .. kc+64) x [col0 .. col0+64), zero-filled outside
+        // stage B[kc .. kc+SLAB) x [col0 .. col0+64), zero-filled outside
         if (g.sbc == 1) {
-            for (int e = threadIdx.x; e < kChunkK * kTileCols; e += 256) {
+            for (int e = threadIdx.x; e < SLAB * kTileCols; e += 256) {
                 const int kk = e >> 6, c = e & 63;
                 const bool ok = (kc + kk < g.K) && (col0 + c < g.Nc);
                 lds[kk * kLdB + c] = ok ? g.B[(int64_t)(kc + kk) * g.sbk + (col0 + c)] : 0.f;
             }
         } else {
-            for (int e = threadIdx.x; e < kChunkK * kTileCols; e += 256) {
-                const int c = e >> 6, kk = e & 63;
+            for (int e = threadIdx.x; e < SLAB * kTileCols; e += 256) {
+                const int c = e / SLAB, kk = e % SLAB;
                 const bool ok = (kc + kk < g.K) && (col0 + c < g.Nc);
                 lds[kk * kLdB + c] = ok ? g.B[(int64_t)(kc + kk) * g.sbk + (int64_t)(col0 + c) * g.sbc] : 0.f;
             }
         }
         __syncthreads();
-        // A fragments of this slab: lane (m, kq) takes k = kc + 16*s + 4*kq + t, t = 0..3
-        float a[4][2][4];
+        // A fragments of this slab: lane (m, kq) takes k = kc + wk + 16*s + 4*kq + t, t = 0..3
+        float a[S][2][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < S; ++s) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                const int k = kc + 16 * s + 4 * kq;
+                const int k = kc + wk + 16 * s + 4 * kq;
                 if (VEC) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (rok[mt] && k < g.K) v = *reinterpret_cast<const float4 *>(g.A + arow[mt] * g.lda + k);
@@ -99,10 +108,10 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
             }
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < S; ++s) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float *brow = lds + (16 * s + 4 * kq + t) * kLdB + m;
+                const float *brow = lds + (wk + 16 * s + 4 * kq + t) * kLdB + m;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const float b = brow[16 * nt];
@@ -116,13 +125,30 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
 
     // C tile through LDS so that global stores are whole-row float4 runs
     __syncthreads();
+    if constexpr (SPLITK) {
+        for (int w = 0; w < 4; ++w) {                  // the four K-quarters, added in wave order
+            if (wave == w) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+                    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lds[(wave * 32 + mt * 16 + 4 * kq + r) * kLdB + 16 * nt + m] = acc[mt][nt][r];
-    __syncthreads();
+                        for (int r = 0; r < 4; ++r) {
+                            float *p = lds + (mt * 16 + 4 * kq + r) * kLdB + 16 * nt + m;
+                            *p = (w == 0) ? acc[mt][nt][r] : *p + acc[mt][nt][r];
+                        }
+            }
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds[(wave * 32 + mt * 16 + 4 * kq + r) * kLdB + 16 * nt + m] = acc[mt][nt][r];
+        __syncthreads();
+    }
 
     const int c4 = threadIdx.x & 15;
     const int col = col0 + 4 * c4;
@@ -144,7 +170,7 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
         head = c4 / g.LPH;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < ROWS / 16; ++i) {
         const int rl = (threadIdx.x >> 4) + 16 * i;
         const int64_t row = row0 + rl;
         float4 v = *reinterpret_cast<const float4 *>(lds + rl * kLdB + 4 * c4);
@@ -596,10 +622,19 @@ static int launch_tall_gemm(const GemmArgs &g, hipStream_t st, const char *name)
             default: return launch_resident<8>(g, st, name);
         }
     }
-    const dim3 grid((unsigned)((g.n + kTileRows - 1) / kTileRows), (unsigned)((g.Nc + kTileCols - 1) / kTileCols));
+    const unsigned gy = (unsigned)((g.Nc + kTileCols - 1) / kTileCols);
     const bool vec = (g.lda % 4 == 0) && (g.K % 4 == 0) && aligned16(g.A);
-    if (vec) hipLaunchKernelGGL(tall_gemm_kernel<true>, grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(tall_gemm_kernel<false>, grid, dim3(256), 0, st, g);
+    // few row blocks and a long K: split K over the waves of smaller blocks
+    const bool splitk = g.K >= 256 && (g.n + kTileRows - 1) / kTileRows * gy < 512;
+    if (splitk) {
+        const dim3 grid((unsigned)((g.n + 31) / 32), gy);
+        if (vec) hipLaunchKernelGGL((tall_gemm_kernel<true, true>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((tall_gemm_kernel<false, true>), grid, dim3(256), 0, st, g);
+    } else {
+        const dim3 grid((unsigned)((g.n + kTileRows - 1) / kTileRows), gy);
+        if (vec) hipLaunchKernelGGL((tall_gemm_kernel<true, false>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((tall_gemm_kernel<false, false>), grid, dim3(256), 0, st, g);
+    }
     GATMI_LAUNCH_CHECK(name);
     return GATMI_OK;
 }
