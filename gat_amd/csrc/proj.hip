@@ -73,51 +73,91 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
         rok[mt] = arow[mt] < g.n;
     }
 
-    for (int kc = 0; kc < g.K; kc += SLAB) {
-        __syncthreads();
-        // stage B[kc .. kc+SLAB) x [col0 .. col0+64), zero-filled outside
-        if (g.sbc == 1) {
-            for (int e = threadIdx.x; e < SLAB * kTileCols; e += 256) {
-                const int kk = e >> 6, c = e & 63;
-                const bool ok = (kc + kk < g.K) && (col0 + c < g.Nc);
-                lds[kk * kLdB + c] = ok ? g.B[(int64_t)(kc + kk) * g.sbk + (col0 + c)] : 0.f;
+    if constexpr (SPLITK) {
+        // No staging and no barrier: B is small and sits in L2, every wave fetches its own fragments
+        // (lane (m, kq) holds B[k = .. + 4*kq + t][col0 + 16*nt + m]); the 32 B loads and 4 A loads of
+        // a step are independent, so one round trip covers them all.
+        for (int kc = wk; kc < g.K; kc += SLAB) {
+            float a[S][2][4], b[S][4][4];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int k = kc + 16 * s + 4 * kq;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    if (VEC) {
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (rok[mt] && k < g.K) v = *reinterpret_cast<const float4 *>(g.A + arow[mt] * g.lda + k);
+                        a[s][mt][0] = v.x; a[s][mt][1] = v.y; a[s][mt][2] = v.z; a[s][mt][3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) a[s][mt][t] = (rok[mt] && k + t < g.K) ? g.A[arow[mt] * g.lda + k + t] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int c = col0 + 16 * nt + m;
+                        b[s][t][nt] = (k + t < g.K && c < g.Nc) ? g.B[(int64_t)(k + t) * g.sbk + (int64_t)c * g.sbc] : 0.f;
+                    }
             }
-        } else {
-            for (int e = threadIdx.x; e < SLAB * kTileCols; e += 256) {
-                const int c = e / SLAB, kk = e % SLAB;
-                const bool ok = (kc + kk < g.K) && (col0 + c < g.Nc);
-                lds[kk * kLdB + c] = ok ? g.B[(int64_t)(kc + kk) * g.sbk + (int64_t)(col0 + c) * g.sbc] : 0.f;
-            }
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][mt][t], b[s][t][nt], acc[mt][nt], 0, 0, 0);
         }
-        __syncthreads();
-        // A fragments of this slab: lane (m, kq) takes k = kc + wk + 16*s + 4*kq + t, t = 0..3
-        float a[S][2][4];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int k = kc + wk + 16 * s + 4 * kq;
-                if (VEC) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (rok[mt] && k < g.K) v = *reinterpret_cast<const float4 *>(g.A + arow[mt] * g.lda + k);
-                    a[s][mt][0] = v.x; a[s][mt][1] = v.y; a[s][mt][2] = v.z; a[s][mt][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) a[s][mt][t] = (rok[mt] && k + t < g.K) ? g.A[arow[mt] * g.lda + k + t] : 0.f;
+    } else {
+        for (int kc = 0; kc < g.K; kc += SLAB) {
+            __syncthreads();
+            // stage B[kc .. kc+SLAB) x [col0 .. col0+64), zero-filled outside
+            if (g.sbc == 1) {
+                for (int e = threadIdx.x; e < SLAB * kTileCols; e += 256) {
+                    const int kk = e >> 6, c = e & 63;
+                    const bool ok = (kc + kk < g.K) && (col0 + c < g.Nc);
+                    lds[kk * kLdB + c] = ok ? g.B[(int64_t)(kc + kk) * g.sbk + (col0 + c)] : 0.f;
+                }
+            } else {
+                for (int e = threadIdx.x; e < SLAB * kTileCols; e += 256) {
+                    const int c = e / SLAB, kk = e % SLAB;
+                    const bool ok = (kc + kk < g.K) && (col0 + c < g.Nc);
+                    lds[kk * kLdB + c] = ok ? g.B[(int64_t)(kc + kk) * g.sbk + (int64_t)(col0 + c) * g.sbc] : 0.f;
                 }
             }
-        }
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float *brow = lds + (wk + 16 * s + 4 * kq + t) * kLdB + m;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const float b = brow[16 * nt];
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][mt][t], b, acc[mt][nt], 0, 0, 0);
+            __syncthreads();
+            // A fragments of this slab: lane (m, kq) takes k = kc + wk + 16*s + 4*kq + t, t = 0..3
+            float a[S][2][4];
+    #pragma unroll
+            for (int s = 0; s < S; ++s) {
+    #pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int k = kc + wk + 16 * s + 4 * kq;
+                    if (VEC) {
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (rok[mt] && k < g.K) v = *reinterpret_cast<const float4 *>(g.A + arow[mt] * g.lda + k);
+                        a[s][mt][0] = v.x; a[s][mt][1] = v.y; a[s][mt][2] = v.z; a[s][mt][3] = v.w;
+                    } else {
+    #pragma unroll
+                        for (int t = 0; t < 4; ++t) a[s][mt][t] = (rok[mt] && k + t < g.K) ? g.A[arow[mt] * g.lda + k + t] : 0.f;
+                    }
+                }
+            }
+    #pragma unroll
+            for (int s = 0; s < S; ++s) {
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float *brow = lds + (wk + 16 * s + 4 * kq + t) * kLdB + m;
+    #pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const float b = brow[16 * nt];
+    #pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][mt][t], b, acc[mt][nt], 0, 0, 0);
+                    }
                 }
             }
         }
