@@ -249,6 +249,25 @@ def _use_mask_lists(cfg, bias_mat):
     return d is not None and d <= MASK_LIST_DENSITY
 
 
+def _widen_for_lists(cfg, bias_mat):
+    """Narrow rows (fewer than 32 floats: a single 7-class output head) cannot use the list kernels,
+    and on one large graph the matrix-core kernels get few blocks.  For a very sparse mask it pays to
+    zero-pad the head width so that a row has 32 floats and take the list kernels: returns such a
+    copy of cfg, or cfg itself.  Only in mask_path="auto" (padding changes the keys of the in-kernel
+    feature dropout, which the forced paths keep stable)."""
+    N = bias_mat.shape[1]
+    if cfg.mask_path != "auto" or cfg.H * cfg.dp >= 32 or not (512 <= N <= 32767):
+        return cfg
+    d = _mask_density(bias_mat)
+    if d is None or d > 0.05:
+        return cfg
+    wide = _Cfg()
+    for k in _Cfg.__slots__:
+        setattr(wide, k, getattr(cfg, k))
+    wide.dp = 32 // cfg.H
+    return wide
+
+
 class DenseGATLayerFn(torch.autograd.Function):
     """Same layer on [B, N, F] inputs with an additive [B, N, N] mask (utils/layers.py:6-34)."""
 
@@ -262,6 +281,7 @@ class DenseGATLayerFn(torch.autograd.Function):
         bias_mat = _f32(bias_mat).contiguous()
         if tuple(bias_mat.shape) != (B, N, N):
             raise ValueError("bias_mat must be [B,N,N] = [%d,%d,%d], got %s" % (B, N, N, tuple(bias_mat.shape)))
+        cfg = _widen_for_lists(cfg, bias_mat)
         H, D, dp = cfg.H, cfg.D, cfg.dp
         hd = H * dp
         st = _lib.current_stream()

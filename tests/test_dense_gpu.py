@@ -205,3 +205,29 @@ def test_hard_mask_as_block_diagonal_graph():
         CSRGraph.from_bias_mat(torch.tensor(_masks(1, 20, 0.2, 2, soft=True), dtype=torch.float32, device=dev))
     with pytest.raises(ValueError):
         m(x[:, :10], graph, "elu")
+
+
+def test_narrow_output_head_on_one_large_sparse_graph():
+    """A single 7-wide head on a 700-node graph with a 1 % mask: 'auto' zero-pads the head to 32
+    floats and takes the list kernels; results equal the matrix-core path and the oracle."""
+    from gat_amd import ops
+    dev = torch.device("cuda:0")
+    B, N, F, H, D = 1, 700, 12, 1, 7
+    bm = _masks(B, N, 0.01, 5)
+    p = layer_params(F, H, D, seed=6)
+    x = np.random.default_rng(7).normal(0, 1, (B, N, F))
+    bt = torch.tensor(bm, dtype=torch.float32, device=dev)
+    assert ops._widen_for_lists(ops.make_cfg(H, D, "identity"), bt).dp == 32
+    assert ops._widen_for_lists(ops.make_cfg(H, D, "identity", mask_path="dense"), bt).dp == 8
+    outs, grads = {}, {}
+    for path in ("auto", "dense"):
+        tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+        xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
+        out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], bt, ops.make_cfg(H, D, "identity", mask_path=path))
+        out.square().sum().backward()
+        outs[path], grads[path] = out.detach().cpu().numpy(), (xt.grad.cpu().numpy(), tp["W"].grad.cpu().numpy(), tp["a2"].grad.cpu().numpy())
+    assert outs["auto"].shape == (B, N, H * D)
+    assert_close(outs["auto"], ref_numpy.gat_layer_dense(x, p, bm, ref_numpy.identity, "concat"), what="widened head vs oracle")
+    assert_close(outs["auto"], outs["dense"], rtol=2e-6, atol_scale=1e-6, what="widened vs matrix cores")
+    for a, b, name in zip(grads["auto"], grads["dense"], ("dX", "dW", "da2")):
+        assert_close(a, b, rtol=1e-5, atol_scale=5e-6, what="widened " + name)
