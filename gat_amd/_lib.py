@@ -110,5 +110,13 @@ def ptr(t):
     return t.ctypes.data
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream():
+    """Handle of the HIP stream torch currently records on (the hipStream_t the kernels are enqueued
+    on).  The raw accessor avoids building a torch.cuda.Stream object per call (about 10 us each, a
+    visible share of a launch-bound step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
