@@ -2,7 +2,8 @@
 send-list handshake, forward halo gather and reverse scatter-add.  The HIP pack / unpack kernels
 cannot run without a GPU, so this test swaps them for torch index ops (stand-ins that exist only
 here) and runs the oracle's math on each rank's shard: the partitioned result must equal the
-single-graph oracle result, forward and backward."""
+single-graph oracle result, forward and backward — with the per-step exchange of projected rows and
+with the first-layer mode that fetches the halo sources' input rows once and exchanges nothing else."""
 import os
 import sys
 
@@ -118,6 +119,26 @@ def _worker(rank, world, port, n, seed, q):
         np.testing.assert_allclose(gx.numpy(), rx.grad.numpy(), rtol=1e-10, atol=1e-12)
         for k in p:
             np.testing.assert_allclose(tp[k].grad.numpy(), rp[k].grad.numpy(), rtol=1e-10, atol=1e-12, err_msg=k)
+        # first-layer mode: the halo sources' INPUT rows fetched once, everything else local; each rank's
+        # parameter gradients are its shares over owned + halo rows and the all-reduce completes them
+        xfull = torch.cat([torch.tensor(x[lo:hi]), torch.zeros(len(halo), F, dtype=torch.float64)])
+        ex.gather_halo(xfull, F)
+        assert torch.equal(xfull[hi - lo:], torch.tensor(x)[torch.as_tensor(halo)])
+        tp2 = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
+        wh2 = (xfull @ tp2["W"].reshape(F, H * D)).reshape(-1, H, D)
+        f1b = (wh2[: hi - lo] * tp2["a1"]).sum(-1) + tp2["b1"]
+        f2b = (wh2 * tp2["a2"]).sum(-1) + tp2["b2"]
+        e2 = torch.nn.functional.leaky_relu(f1b[dsts] + f2b[col_local.long()], 0.2)
+        m2 = torch.full((hi - lo, H), -1e30, dtype=torch.float64).scatter_reduce(0, dsts[:, None].expand(-1, H), e2.detach(), "amax")
+        p2 = torch.exp(e2 - m2[dsts])
+        a2_ = p2 / torch.zeros((hi - lo, H), dtype=torch.float64).index_add(0, dsts, p2)[dsts]
+        out2 = torch.zeros((hi - lo, H, D), dtype=torch.float64).index_add(0, dsts, a2_[:, :, None] * wh2[col_local.long()])
+        out2 = torch.nn.functional.elu(out2 + tp2["bias"]).reshape(hi - lo, H * D)
+        out2.backward(dout[lo:hi])
+        gdist.allreduce_grads(list(tp2.values()))
+        np.testing.assert_allclose(out2.detach().numpy(), ref.detach().numpy()[lo:hi], rtol=1e-11, atol=1e-12)
+        for k in p:
+            np.testing.assert_allclose(tp2[k].grad.numpy(), rp[k].grad.numpy(), rtol=1e-10, atol=1e-12, err_msg="replicate " + k)
         q.put((rank, "ok"))
     except Exception as exc:  # noqa: BLE001
         import traceback
