@@ -82,8 +82,8 @@ def test_attn_e2v_bnf_v2_composition(F, out_sz, heads, residual):
     aggall.backward(torch.tensor(g, dtype=torch.float32, device=dev))
     ragg.backward(torch.tensor(g))
     assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), rtol=1e-4, atol_scale=5e-5, what="e2v dX")
-    assert_close(mod.att[0].W.grad.cpu().numpy(), rounds[0]["W"].grad.numpy(), rtol=1e-4, atol_scale=5e-5, what="e2v dW(round 0)")
-    assert_close(mod.att[4].m1.grad.cpu().numpy(), rounds[4]["m1"].grad.numpy(), rtol=1e-4, atol_scale=5e-5, what="e2v dm1(round 4)")
+    assert_close(mod.att[0].W.grad.cpu().numpy(), rounds[0]["W"].grad.numpy(), rtol=1e-4, atol_scale=5e-5, what="e2v dW(repetition 0)")
+    assert_close(mod.att[4].m1.grad.cpu().numpy(), rounds[4]["m1"].grad.numpy(), rtol=1e-4, atol_scale=5e-5, what="e2v dm1(repetition 4)")
 
 
 def test_gat_ae_bnf_v2_model_runs_on_the_kernels():
