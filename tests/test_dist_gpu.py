@@ -140,3 +140,53 @@ def test_two_ranks_on_one_gpu_match_single_gpu():
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def _nccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from gat_amd import dist as gdist
+        # the collectives of the partitioned layer in the forms it issues them, on RCCL with one rank
+        ex = gdist.HaloExchange.__new__(gdist.HaloExchange)
+        ex.rank, ex.world, ex.group, ex.device, ex.backend = 0, 1, None, dev, dist.get_backend()
+        assert ex.backend == "nccl"
+        rows = torch.randn(37, 64, device=dev)
+        out = torch.empty_like(rows)
+        ex._a2a(out, rows, [37], [37])                         # device rows, uneven-split form
+        ids = torch.arange(11, dtype=torch.int64)
+        got = torch.empty(11, dtype=torch.int64)
+        ex._a2a(got, ids, [11], [11])                          # host int64 ids staged through the device
+        cnt = torch.empty(1, dtype=torch.int64)
+        ex._a2a(cnt, torch.tensor([5], dtype=torch.int64), None, None)
+        w = torch.nn.Parameter(torch.ones(3, device=dev))
+        w.grad = torch.full((3,), 2.0, device=dev)
+        dist.all_reduce(w.grad)
+        t = torch.tensor([1.5, 2.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert torch.equal(out, rows) and torch.equal(got, ids) and int(cnt) == 5 and float(w.grad[0]) == 2.0
+        q.put("ok")
+    except Exception as exc:  # noqa: BLE001
+        import traceback
+        q.put("FAIL %s\n%s" % (exc, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_rccl_initialises_and_runs_the_collective_forms_on_one_rank():
+    """One GPU cannot host two RCCL ranks, but a one-rank communicator still goes through RCCL's
+    initialisation and the exact call forms of the partitioned layer (all_to_all_single with split
+    lists on device rows and on staged int64 ids, all_reduce SUM / MAX, barrier)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(31500 + os.getpid() % 2000, q))
+    p.start()
+    msg = q.get(timeout=240)
+    p.join(timeout=60)
+    assert msg == "ok", msg
