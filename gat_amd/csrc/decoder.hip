@@ -167,6 +167,18 @@ constexpr size_t kGraphLdsMax = 80 * 1024;
 template <int NTF>
 __device__ __forceinline__ void ipd_stage_graph(const IpdArgs &a, int64_t b, int Np, float *zs) {
     using S = IpdShape<NTF>;
+    if ((a.F & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Z) & 15) == 0) {      // rows are 16-byte aligned: four columns per load
+        for (int e = threadIdx.x; e < Np * (S::FP / 4); e += 64 * kGraphWaves) {
+            const int r = e / (S::FP / 4), c = 4 * (e % (S::FP / 4));
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < a.N && c < a.F) {
+                v = *reinterpret_cast<const float4 *>(a.Z + (b * a.N + r) * (int64_t)a.F + c);
+                if (a.keep < 1.f) v = drop_feat(v, a.seed, b * a.N + r, a.F, c, a.keep);
+            }
+            *reinterpret_cast<float4 *>(zs + r * S::LD + c) = v;
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < Np * S::FP; e += 64 * kGraphWaves) {
         const int r = e / S::FP, c = e % S::FP;
         float v = 0.f;
