@@ -243,6 +243,8 @@ __global__ __launch_bounds__(64 * kGraphWaves) void ipd_bwd_graph_kernel(IpdArgs
     __syncthreads();
     const float *gmat = a.dOut + b * N * (int64_t)N;
     const float *omat = a.out_saved ? a.out_saved + b * N * (int64_t)N : nullptr;
+    const bool vec = (N & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dOut) & 15) == 0 &&
+                     (!a.out_saved || (reinterpret_cast<uintptr_t>(a.out_saved) & 15) == 0);
     for (int it = blockIdx.y * kGraphWaves + wave; it < nt; it += gridDim.y * kGraphWaves) {
         const int i0 = 16 * it;
         const bool iok = i0 + m < N;
@@ -253,14 +255,27 @@ __global__ __launch_bounds__(64 * kGraphWaves) void ipd_bwd_graph_kernel(IpdArgs
         for (int j0 = 0; j0 < Np; j0 += 32) {
             float gd[2][4], gt[2][4], ov[2][4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h) {
+                const int jb = j0 + 16 * h + 4 * kq;
+                if (vec && jb + 3 < N) {                  // rows are 16-byte aligned: the direct reads are one load each
+                    const float4 g4 = *reinterpret_cast<const float4 *>(gmat + irow * (uint32_t)N + jb);
+                    gd[h][0] = g4.x; gd[h][1] = g4.y; gd[h][2] = g4.z; gd[h][3] = g4.w;
+                    if (omat) {
+                        const float4 o4 = *reinterpret_cast<const float4 *>(omat + irow * (uint32_t)N + jb);
+                        ov[h][0] = o4.x; ov[h][1] = o4.y; ov[h][2] = o4.z; ov[h][3] = o4.w;
+                    }
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const uint32_t j = (uint32_t)min(j0 + 16 * h + 4 * kq + s, N - 1);
-                    gd[h][s] = gmat[irow * (uint32_t)N + j];
-                    gt[h][s] = gmat[j * (uint32_t)N + irow];
-                    ov[h][s] = omat ? omat[irow * (uint32_t)N + j] : 0.5f;
+                    for (int s = 0; s < 4; ++s) gt[h][s] = gmat[(uint32_t)(jb + s) * (uint32_t)N + irow];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const uint32_t j = (uint32_t)min(jb + s, N - 1);
+                        gd[h][s] = gmat[irow * (uint32_t)N + j];
+                        gt[h][s] = gmat[j * (uint32_t)N + irow];
+                        ov[h][s] = omat ? omat[irow * (uint32_t)N + j] : 0.5f;
+                    }
                 }
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (j0 + 16 * h >= Np) break;
