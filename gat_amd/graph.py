@@ -152,16 +152,19 @@ class CSRGraph:
         block-diagonal graph over B*N nodes: entry (b,i,j) is kept iff it lies within `cutoff` of its
         row's maximum (anything lower has a softmax coefficient of exactly 0 in fp32).  Build it
         once for a mask that is used step after step and pass it where bias_mat went: the layer then
-        runs the CSR kernels and never reads the N x N floats again.  Only for hard masks: every kept
-        entry must be 0 (a kept non-zero bias would have to be added to the logits, which the CSR
-        kernels do not do) -- ValueError otherwise."""
+        runs the CSR kernels and never reads the N x N floats again.  Only for hard masks: the kept
+        entries of a row must all carry the same bias (0 in an adj_to_bias mask, +1e9 on the diagonal
+        of a padded node: a constant shift of a row's logits cancels in its softmax); biases that
+        differ inside a row would have to be added to the logits, which the CSR kernels do not do --
+        ValueError then."""
         if bias_mat.dim() != 3 or bias_mat.shape[1] != bias_mat.shape[2] or not bias_mat.is_cuda:
             raise ValueError("from_bias_mat: a [B,N,N] device tensor is expected")
         B, N, _ = bias_mat.shape
-        keep = bias_mat > bias_mat.amax(-1, keepdim=True) - cutoff
-        if bool((bias_mat[keep] != 0).any()):
-            raise ValueError("from_bias_mat: the mask carries non-zero biases on entries that contribute; "
-                             "keep it dense (attn_head adds them to the logits)")
+        rowmax = bias_mat.amax(-1, keepdim=True)
+        keep = bias_mat > rowmax - cutoff
+        if bool(((bias_mat != rowmax) & keep).any()):
+            raise ValueError("from_bias_mat: the mask carries different biases on the entries of a row that "
+                             "contribute; keep it dense (attn_head adds them to the logits)")
         b, i, j = keep.nonzero(as_tuple=True)
         del keep
         base = b * N

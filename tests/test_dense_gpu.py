@@ -203,6 +203,15 @@ def test_hard_mask_as_block_diagonal_graph():
         assert_close(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-5, atol_scale=5e-6, what="graph vs mask " + name)
     with pytest.raises(ValueError):
         CSRGraph.from_bias_mat(torch.tensor(_masks(1, 20, 0.2, 2, soft=True), dtype=torch.float32, device=dev))
+    # a padded batch (+1e9 on the diagonal of padded nodes, utils/process.py:14-25 with sizes) is a hard mask too
+    from gat_amd import preprocess
+    rng = np.random.default_rng(1)
+    adjs = [np.maximum(a, a.T) for a in ((rng.random((k, k)) < 0.2).astype(np.float64) for k in (9, 20, 14))]
+    adj, feats, sizes, _ = preprocess.pad_graphs(adjs, [rng.normal(0, 1, (a.shape[0], F)) for a in adjs])
+    pbm = torch.tensor(preprocess.adj_to_bias(adj, sizes), dtype=torch.float32, device=dev)
+    px = torch.tensor(feats, dtype=torch.float32, device=dev)
+    pa, pb = m(px, CSRGraph.from_bias_mat(pbm), "elu"), m(px, pbm, "elu")
+    assert_close(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-6, atol_scale=1e-6, what="padded batch as a graph")
     with pytest.raises(ValueError):
         m(x[:, :10], graph, "elu")
 
