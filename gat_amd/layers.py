@@ -14,6 +14,7 @@ tf.add_n / n (models/sp_gat.py:12-17, 27-32): one kernel sweep for all heads.
 """
 import contextlib
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -36,6 +37,45 @@ def _activation_name(activation):
     if name == "<lambda>" or name == "identity":
         return "identity"
     raise ValueError("unsupported activation %r: the kernels fuse ELU, ReLU or the identity" % (activation,))
+
+
+class _MaskGraphs:
+    """Memo of block-diagonal graphs for dense masks that are passed again and again.
+
+    The reference feeds the same bias_mat every step.  When a mask tensor is seen a second time
+    unchanged (same tensor object, same version counter), is hard and sparse, it is converted once
+    with CSRGraph.from_bias_mat and the layer runs the CSR kernels from then on (about twice as fast
+    as re-reading the N x N floats at a density of 10 %).  The memo keys on the tensor OBJECT through
+    a weak reference, so a different tensor that happens to reuse the address is never mistaken for
+    it, and any in-place change (version counter) drops the entry.  `enabled = False` switches it off."""
+
+    def __init__(self):
+        self.enabled = True
+        self._entries = {}          # id(tensor) -> [weakref, version, graph | None (not decided) | False (stay dense)]
+
+    def lookup(self, t):
+        if not self.enabled or not torch.is_tensor(t) or t.dim() != 3 or not t.is_cuda:
+            return None
+        e = self._entries.get(id(t))
+        if e is None or e[0]() is not t or e[1] != t._version:
+            if len(self._entries) > 16:
+                self._entries = {k: v for k, v in self._entries.items() if v[0]() is not None}
+            self._entries[id(t)] = [weakref.ref(t), t._version, None]
+            return None
+        if e[2] is None:             # second sighting: decide
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            d = ops._mask_density(t)
+            e[2] = False
+            if d is not None and d <= ops.MASK_LIST_DENSITY:
+                try:
+                    e[2] = CSRGraph.from_bias_mat(t)
+                except ValueError:   # biases differ inside a row: the dense kernels add them
+                    pass
+        return e[2] or None
+
+
+mask_graphs = _MaskGraphs()
 
 
 class GATHeads(nn.Module):
@@ -101,6 +141,9 @@ class GATHeads(nn.Module):
             if seed is None and training and (in_drop > 0.0 or coef_drop > 0.0):
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             return self._run(seq, graph_or_bias, slice(0, H), act, reduce, in_drop, coef_drop, training, seed)[None]
+        g = mask_graphs.lookup(graph_or_bias)                                # a dense mask met before, unchanged
+        if g is not None and seq.dim() == 3:
+            return self.forward(seq, g, act, reduce, in_drop, coef_drop, training, seed)
         if training and in_drop > 0.0:
             seq = torch.nn.functional.dropout(seq, in_drop, True)            # layers.py:8-9
         if seed is None and training and (in_drop > 0.0 or coef_drop > 0.0):

@@ -240,3 +240,36 @@ def test_narrow_output_head_on_one_large_sparse_graph():
     assert_close(outs["auto"], outs["dense"], rtol=2e-6, atol_scale=1e-6, what="widened vs matrix cores")
     for a, b, name in zip(grads["auto"], grads["dense"], ("dX", "dW", "da2")):
         assert_close(a, b, rtol=1e-5, atol_scale=5e-6, what="widened " + name)
+
+
+def test_repeated_hard_mask_is_converted_once_and_tracks_changes():
+    """GATHeads keeps a memo of masks it has met: the second unchanged sighting of a sparse hard mask
+    builds the block-diagonal graph, later calls use it, an in-place change of the mask drops it."""
+    from gat_amd import layers
+    from gat_amd.layers import GATHeads
+    dev = torch.device("cuda:0")
+    B, N, F, H, D = 4, 60, 8, 8, 8
+    bm = torch.tensor(_masks(B, N, 0.1, 9), dtype=torch.float32, device=dev)
+    x = torch.tensor(np.random.default_rng(0).normal(0, 1, (B, N, F)), dtype=torch.float32, device=dev)
+    m = GATHeads(F, H, D, device=dev)
+    m.load(layer_params(F, H, D, seed=2))
+    layers.mask_graphs._entries.clear()
+    first = m(x, bm, "elu")
+    assert layers.mask_graphs.lookup(bm) is not None            # second sighting converts
+    third = m(x, bm, "elu")
+    assert_close(third.detach().cpu().numpy(), first.detach().cpu().numpy(), rtol=2e-6, atol_scale=1e-6, what="graph vs kernels")
+    bm[0, 3, :] = 0.0                                             # node 3 of graph 0 now attends to everybody
+    assert layers.mask_graphs.lookup(bm) is None                # version changed: entry dropped, dense kernels again
+    changed = m(x, bm, "elu")
+    assert (changed[0, 3] - first[0, 3]).abs().max() > 1e-4 and torch.allclose(changed[1:], first[1:], atol=1e-6)
+    again = m(x, bm, "elu")                                       # converted anew from the changed mask
+    assert_close(again.detach().cpu().numpy(), changed.detach().cpu().numpy(), rtol=2e-6, atol_scale=1e-6, what="after the change")
+    soft = torch.tensor(_masks(2, 30, 0.2, 4, soft=True), dtype=torch.float32, device=dev)
+    xs = x[:2, :30]
+    a, b2, c = m(xs, soft, "elu"), m(xs, soft, "elu"), m(xs, soft, "elu")      # soft masks stay with the dense kernels
+    assert torch.equal(a, b2) and torch.equal(b2, c)
+    layers.mask_graphs.enabled = False
+    try:
+        assert layers.mask_graphs.lookup(bm) is None
+    finally:
+        layers.mask_graphs.enabled = True
