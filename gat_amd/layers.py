@@ -53,6 +53,12 @@ class _MaskGraphs:
         self.enabled = True
         self._entries = {}          # id(tensor) -> [weakref, version, graph | None (not decided) | False (stay dense)]
 
+    def _drop(self, key, ref):
+        """The mask tensor died: release its graph (unless the id was taken by a newer entry)."""
+        e = self._entries.get(key)
+        if e is not None and e[0] is ref:
+            del self._entries[key]
+
     def lookup(self, t):
         if not self.enabled or not torch.is_tensor(t) or t.dim() != 3 or not t.is_cuda:
             return None
@@ -60,7 +66,8 @@ class _MaskGraphs:
         if e is None or e[0]() is not t or e[1] != t._version:
             if len(self._entries) > 16:
                 self._entries = {k: v for k, v in self._entries.items() if v[0]() is not None}
-            self._entries[id(t)] = [weakref.ref(t), t._version, None]
+            key = id(t)
+            self._entries[key] = [weakref.ref(t, lambda _r, k=key: self._drop(k, _r)), t._version, None]
             return None
         if e[2] is None:             # second sighting: decide
             if torch.cuda.is_current_stream_capturing():
