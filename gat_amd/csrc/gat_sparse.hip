@@ -120,7 +120,9 @@ __device__ __forceinline__ void fwd_finish(const RowState &st, const FwdArgs &a,
     float4 r = ag;
     if (a.bias) r = f4_add(r, *reinterpret_cast<const float4 *>(a.bias + sub * 4));
     if (a.reduce == GATMI_REDUCE_MEAN) {
-        // identity activation only (checked on the host): mean over heads of (agg + bias)
+        // identity activation only (checked on the host): mean over heads of (agg + bias + resid);
+        // the residual projection is per head ([n, hd], utils/layers.py:30), so it is averaged too
+        if (a.resid) r = f4_add(r, *reinterpret_cast<const float4 *>(a.resid + row * HD + sub * 4));
 #pragma unroll
         for (int o = LPH; o < G; o <<= 1) {
             r.x += __shfl_xor(r.x, o, 64);
@@ -130,7 +132,6 @@ __device__ __forceinline__ void fwd_finish(const RowState &st, const FwdArgs &a,
         }
         if (sub < LPH) {
             r = f4_scale(1.0f / H, r);
-            if (a.resid) r = f4_add(r, *reinterpret_cast<const float4 *>(a.resid + row * (4 * LPH) + sub * 4));
             *reinterpret_cast<float4 *>(a.out + row * (4 * LPH) + sub * 4) = r;
         }
         return;

@@ -15,6 +15,7 @@ from . import _lib
 DEFAULT_CHUNK = 0          # 0 = choose from the entry count (auto_chunk)
 MIN_CHUNK, MAX_CHUNK = 256, 4096
 RESIDENT_ROW_GROUPS = 32768   # 256 CUs x 32 waves x 4 row groups of 16 lanes
+SHARED_BIAS_LIMIT = 16.0      # from_bias_mat: largest |bias| shared by a row's kept entries (fp32 spacing there: 2e-6)
 
 
 def auto_chunk(nnz):
@@ -34,6 +35,9 @@ def _work_items(ptr_host, chunk, order="length"):
     a batch of small graphs wants; a power-law graph wants the length sort."""
     n = len(ptr_host) - 1
     ptr_host = np.ascontiguousarray(ptr_host, dtype=np.int64)
+    if n >= 2 ** 31 or (n > 0 and int(ptr_host[-1]) >= 2 ** 31):
+        raise _lib.GatmiError("work items: %d rows / %d entries do not fit the kernels' 32-bit offsets "
+                              "(one GPU's shard must stay below 2^31 of each)" % (n, int(ptr_host[-1]) if n > 0 else 0))
     if order == "rows" and n > 0 and int(np.diff(ptr_host).max()) <= chunk:
         items = np.empty((n, 4), dtype=np.int32)
         items[:, 0] = np.arange(n, dtype=np.int32)
@@ -131,6 +135,9 @@ class CSRGraph:
         pairs.  Sorting runs on the device; only the two pointer arrays visit the host (for the
         work-item builder).  Produces the same arrays as the host path."""
         dev = dst.device
+        if max(n_dst, n_src) >= 2 ** 31 or dst.numel() >= 2 ** 31:
+            raise _lib.GatmiError("from_device_coo: %d x %d nodes / %d entries do not fit the kernels' 32-bit ids and "
+                                  "offsets" % (n_dst, n_src, dst.numel()))
         key = dst * n_src + src
         key, _ = torch.sort(key)
         d = torch.div(key, n_src, rounding_mode="floor")
@@ -156,7 +163,9 @@ class CSRGraph:
         entries of a row must all carry the same bias (0 in an adj_to_bias mask, +1e9 on the diagonal
         of a padded node: a constant shift of a row's logits cancels in its softmax); biases that
         differ inside a row would have to be added to the logits, which the CSR kernels do not do --
-        ValueError then."""
+        ValueError then.  ValueError too for a row that keeps several entries under one LARGE bias (a
+        row masked everywhere): in fp32 the bias swallows the logits and the row attends uniformly,
+        which the CSR kernels would not reproduce."""
         if bias_mat.dim() != 3 or bias_mat.shape[1] != bias_mat.shape[2] or not bias_mat.is_cuda:
             raise ValueError("from_bias_mat: a [B,N,N] device tensor is expected")
         B, N, _ = bias_mat.shape
@@ -165,6 +174,14 @@ class CSRGraph:
         if bool(((bias_mat != rowmax) & keep).any()):
             raise ValueError("from_bias_mat: the mask carries different biases on the entries of a row that "
                              "contribute; keep it dense (attn_head adds them to the logits)")
+        # A shared bias cancels in the softmax only while fp32 can still resolve the logits next to it:
+        # LeakyReLU(z) + bias is rounded to the spacing of fp32 at |bias| (utils/layers.py:17), and a row
+        # that is masked everywhere (-1e9 in every column) swallows its logits and attends uniformly.
+        # Rows that keep a single entry (a padded node's +1e9 diagonal) have coefficient 1 either way.
+        if bool(((rowmax.abs() > SHARED_BIAS_LIMIT) & (keep.sum(-1, keepdim=True) > 1)).any()):
+            raise ValueError("from_bias_mat: a row keeps several entries under a shared bias beyond %g in magnitude "
+                             "(e.g. a row masked everywhere): fp32 rounds its logits away, which only the dense "
+                             "kernels reproduce; keep it dense" % SHARED_BIAS_LIMIT)
         b, i, j = keep.nonzero(as_tuple=True)
         del keep
         base = b * N

@@ -13,7 +13,13 @@ def capture(step, warmup=3):
     one-off mask statistics of the dense layer), capture one more call into a HIP graph and return
     (replay, result): `replay()` re-runs the captured kernels on the tensors the capture used — update
     inputs in place (`x.copy_(...)`) before replaying and read outputs from the same tensors after —
-    and `result` is whatever the captured call returned."""
+    and `result` is whatever the captured call returned.
+
+    Dropout: the kernels receive the dropout seed BY VALUE (drawn on the host when the step is
+    issued), so a captured step replays the SAME coefficient and projected-feature masks
+    (utils/layers.py:20,22) on every replay; only torch's own dropout of the layer input (:9)
+    advances its generator under replay.  Capture steps whose dropout rates are 0 (evaluation, the
+    benchmarks) or accept fixed masks; for fresh masks every step run eagerly."""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):

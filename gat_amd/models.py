@@ -144,10 +144,10 @@ def _compose(head_fn, inputs, nb_classes, training, attn_drop, ffd_drop, graph, 
 
 
 def _is_training(training, attn_drop, ffd_drop):
-    """The reference feeds dropout 0.0 at evaluation time (execute_cora.py:123) and ignores the
-    `training` argument; here either signal switches dropout off."""
-    if isinstance(training, bool):
-        return training and (attn_drop != 0.0 or ffd_drop != 0.0)
+    """Whether dropout acts.  As in the reference, `training` is accepted and NOT consulted
+    (models/gat.py:8 never reads it): a rate other than 0 drops (utils/layers.py:8,19,21 test the
+    rate itself), and evaluation feeds 0.0 for both rates (execute_cora.py:123)."""
+    del training
     return attn_drop != 0.0 or ffd_drop != 0.0
 
 

@@ -165,7 +165,8 @@ int gatmi_proj_bwd_params_csr(const int64_t *xt_rowptr, const int32_t *xt_row, c
  *   items/n_items, split/n_split : gatmi_work_items of the CSR rowptr; col: CSR source ids
  *   feat [n_src, hd] gathered rows (Wh) stored as feat_dtype (GATMI_DTYPE_F32, or GATMI_DTYPE_BF16
  *       written by gatmi_to_bf16: dropout must then be off); f1 [n_dst, H]; f2 [n_src, H]
- *   bias [hd] or NULL; resid [n_dst, hd] or NULL (added before the activation)
+ *   bias [hd] or NULL; resid [n_dst, hd] or NULL (per head, added before the activation; with
+ *       GATMI_REDUCE_MEAN it is averaged over the heads together with the aggregate and the bias)
  *   out [n_dst, hd] (concat) or [n_dst, dp] (mean)
  *   agg, pos [n_dst, hd], lse, q [n_dst, H]: saved for the backward pass, all NULL for inference
  *       agg = sum_j alpha_ij feat_j (before bias), pos = same sum over entries with positive

@@ -273,3 +273,42 @@ def test_repeated_hard_mask_is_converted_once_and_tracks_changes():
         assert layers.mask_graphs.lookup(bm) is None
     finally:
         layers.mask_graphs.enabled = True
+
+
+def test_row_masked_everywhere_stays_with_the_dense_kernels():
+    """A row that is -1e9 in every column attends uniformly in fp32 (the bias swallows the logits,
+    utils/layers.py:17).  The CSR kernels would compute a true softmax over the logits instead, so
+    from_bias_mat refuses such a mask and the memo of repeated masks keeps it dense: the first, second
+    and third call give the same (uniform) row, equal to the forced dense and list routes."""
+    from gat_amd import CSRGraph, layers, ops
+    from gat_amd.layers import GATHeads
+    dev = torch.device("cuda:0")
+    B, N, F, H, D = 3, 48, 7, 8, 8
+    bm = _masks(B, N, 0.1, 12)
+    bm[1, 7, :] = -1e9
+    bt = torch.tensor(bm, dtype=torch.float32, device=dev)
+    with pytest.raises(ValueError):
+        CSRGraph.from_bias_mat(bt)
+    shifted = torch.tensor(_masks(B, N, 0.1, 12), dtype=torch.float32, device=dev)
+    shifted[0, 2] += 1.0e6                                        # a shared 1e6 on a row with several kept entries
+    with pytest.raises(ValueError):
+        CSRGraph.from_bias_mat(shifted)
+    p = layer_params(F, H, D, seed=3)
+    m = GATHeads(F, H, D, device=dev)
+    m.load(p)
+    x = torch.tensor(np.random.default_rng(4).normal(0, 1, (B, N, F)), dtype=torch.float32, device=dev)
+    layers.mask_graphs._entries.clear()
+    calls = [m(x, bt, "elu").detach().cpu().numpy() for _ in range(4)]
+    assert layers.mask_graphs.lookup(bt) is None                 # decided: stays dense
+    for c in calls[1:]:
+        assert np.array_equal(c, calls[0])
+    tp = {k: torch.tensor(v, dtype=torch.float32, device=dev) for k, v in p.items()}
+    for path in ("dense", "lists"):
+        o = ops.dense_gat_layer(x, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], bt,
+                                ops.make_cfg(H, D, "elu", mask_path=path)).cpu().numpy()
+        assert_close(calls[0], o, rtol=2e-6, atol_scale=1e-6, what="memo route vs " + path)
+    wh = x.cpu().numpy().astype(np.float64) @ p["W"].reshape(F, H * D)
+    assert_close(calls[0][1, 7], ref_numpy.elu(wh[1].mean(0) + p["bias"].reshape(-1)), rtol=1e-5, atol_scale=1e-5, what="uniform row")
+    # the oracle evaluated in fp32 (as TensorFlow does) swallows the logits of that row too
+    assert_close(calls[0], ref_numpy.gat_layer_dense(x.cpu().numpy(), p, bm.astype(np.float32), ref_numpy.elu, "concat"),
+                 rtol=1e-5, atol_scale=1e-5, what="fp32 oracle")

@@ -4,6 +4,7 @@ cannot run without a GPU, so this test swaps them for torch index ops (stand-ins
 here) and runs the oracle's math on each rank's shard: the partitioned result must equal the
 single-graph oracle result, forward and backward — with the per-step exchange of projected rows and
 with the first-layer mode that fetches the halo sources' input rows once and exchanges nothing else."""
+import datetime
 import os
 import sys
 
@@ -11,7 +12,6 @@ import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -27,7 +27,7 @@ def _cpu_unpack_add(rows, idx, n_idx, width, table):
 def _worker(rank, world, port, n, seed, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         from gat_amd import dist as gdist, graph
         from oracle import ref_numpy, ref_torch
@@ -149,17 +149,8 @@ def _worker(rank, world, port, n, seed, q):
 
 @pytest.mark.parametrize("world,n,seed", [(2, 61, 0), (2, 200, 1), (3, 97, 2)])
 def test_partitioned_layer_equals_single_graph(world, n, seed):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + (os.getpid() + 7 * seed) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, seed, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=240) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, msg in results:
-        assert msg == "ok", "rank %d: %s" % (rank, msg)
+    from tests.util import run_ranks
+    run_ranks(_worker, world, (n, seed), timeout=240)
 
 
 def test_device_and_host_halo_plans_agree_on_cpu_tensors():

@@ -1,6 +1,7 @@
 """Two ranks sharing the one visible GPU (gloo backend, buffers staged through the host): the
 row-partitioned layer with the real HIP kernels must reproduce the single-GPU layer, forward and
 backward.  (RCCL refuses two ranks on one device; the collectives' plumbing is the same.)"""
+import datetime
 import os
 import sys
 
@@ -8,7 +9,6 @@ import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
     try:
         from gat_amd import CSRGraph, dist as gdist, graph, ops
         from tests.util import assert_close, layer_params, random_graph
@@ -128,27 +128,17 @@ def _worker(rank, world, port, q):
 
 
 def test_two_ranks_on_one_gpu_match_single_gpu():
-    world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, msg in results:
-        assert msg == "ok", "rank %d: %s" % (rank, msg)
+    from tests.util import run_ranks
+    run_ranks(_worker, 2, timeout=300)
 
 
-def _nccl_worker(port, q):
+def _nccl_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     try:
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=200))
         from gat_amd import dist as gdist
         # the collectives of the partitioned layer in the forms it issues them, on RCCL with one rank
         ex = gdist.HaloExchange.__new__(gdist.HaloExchange)
@@ -170,10 +160,10 @@ def _nccl_worker(port, q):
         dist.barrier()
         torch.cuda.synchronize()
         assert torch.equal(out, rows) and torch.equal(got, ids) and int(cnt) == 5 and float(w.grad[0]) == 2.0
-        q.put("ok")
+        q.put((0, "ok"))
     except Exception as exc:  # noqa: BLE001
         import traceback
-        q.put("FAIL %s\n%s" % (exc, traceback.format_exc()))
+        q.put((0, "FAIL %s\n%s" % (exc, traceback.format_exc())))
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -183,10 +173,5 @@ def test_rccl_initialises_and_runs_the_collective_forms_on_one_rank():
     """One GPU cannot host two RCCL ranks, but a one-rank communicator still goes through RCCL's
     initialisation and the exact call forms of the partitioned layer (all_to_all_single with split
     lists on device rows and on staged int64 ids, all_reduce SUM / MAX, barrier)."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_nccl_worker, args=(31500 + os.getpid() % 2000, q))
-    p.start()
-    msg = q.get(timeout=240)
-    p.join(timeout=60)
-    assert msg == "ok", msg
+    from tests.util import run_ranks
+    run_ranks(_nccl_worker, 1, timeout=240)

@@ -56,7 +56,7 @@ def test_sparse_layer_random_draw(seed):
     chunk = int(rng.choice([4, 32, 256, 2048]))
     activation = str(rng.choice(["elu", "relu", "identity"]))
     reduce = "mean" if activation == "identity" and rng.random() < 0.5 else "concat"
-    res = bool(rng.random() < 0.3) and reduce == "concat" and F != D      # equal widths: the reference's residual is a no-op (layers.py:31-32)
+    res = bool(rng.random() < 0.3) and F != D      # equal widths: the reference's residual is a no-op (layers.py:31-32)
     dst, src = random_graph(n, deg, seed=seed, hubs=hubs, hub_deg=min(n, 400))
     p = layer_params(F, H, D, seed=seed + 1, res=res)
     x = rng.normal(0, 1, (n, F))

@@ -113,13 +113,16 @@ def test_hub_rows_are_split_and_merged():
     _check_param_grads(tp, rp, ("W", "a1", "a2", "b1", "b2", "bias"), n)
 
 
-def test_residual_projection():
-    n, F, H, D = 220, 18, 4, 8
+@pytest.mark.parametrize("H,D,activation,reduce", [(4, 8, "elu", "concat"), (4, 8, "identity", "mean"), (2, 7, "identity", "mean")])
+def test_residual_projection(H, D, activation, reduce):
+    """The residual projection is per head (utils/layers.py:30): with reduce="mean" it is averaged
+    over the heads together with the aggregate and the bias."""
+    n, F = 220, 18
     dst, src = random_graph(n, 5.0, seed=21)
-    x, p, tp, xt, out, rowptr, col = _run_layer(n, F, H, D, dst, src, "elu", "concat", seed=31, res=True)
+    x, p, tp, xt, out, rowptr, col = _run_layer(n, F, H, D, dst, src, activation, reduce, seed=31, res=True)
     rp = _oracle_leaves(p, n)
     rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
-    rout = ref_torch.layer_csr(rx, rp, torch.tensor(rowptr), torch.tensor(col), "elu", "concat", residual=True)
+    rout = ref_torch.layer_csr(rx, rp, torch.tensor(rowptr), torch.tensor(col), activation, reduce, residual=True)
     assert_close(out.detach().cpu().numpy(), rout.detach().numpy(), what="forward residual")
     dout = np.random.default_rng(8).normal(0, 1, tuple(out.shape))
     out.backward(torch.tensor(dout, dtype=torch.float32, device=out.device))

@@ -103,3 +103,49 @@ def dense_dropout_masks(seed, B, N, H, D, dp, coef_drop, in_drop):
         idx = np.arange(B * N, dtype=np.uint64)[:, None, None] * np.uint64(H * dp) + cols[None]
         ft = keep_mask_host(seed ^ FEAT_SALT, idx, 1.0 - in_drop).astype(np.float64).reshape(B, N, H, D)
     return coef, ft
+
+
+# ---- multi-process tests -------------------------------------------------------------------------
+def free_port():
+    """A TCP port nobody listens on right now (bound to port 0 and released)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def run_ranks(worker, world, args=(), timeout=300):
+    """Start `worker(rank, world, port, *args, q)` in `world` spawned processes and collect one
+    (rank, message) per process from the queue.  Whatever happens (a worker that dies without
+    reporting, a timeout), every process still alive afterwards is terminated and joined, so no rank
+    stays behind blocked in a collective with the GPU or the port held."""
+    import queue
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = []
+    try:
+        for _ in procs:
+            try:
+                results.append(q.get(timeout=timeout))
+            except queue.Empty:
+                dead = [i for i, p in enumerate(procs) if not p.is_alive()]
+                raise AssertionError("no report within %d s (%d of %d reported; exited ranks: %s, exit codes %s)"
+                                     % (timeout, len(results), world, dead, [procs[i].exitcode for i in dead]))
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+                if p.is_alive():
+                    p.kill()
+                    p.join(timeout=10)
+    for rank, msg in results:
+        assert msg == "ok", "rank %s: %s" % (rank, msg)
+    return results
