@@ -23,11 +23,19 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 #include "device_common.h"
 
 namespace gatmi {
+
+// Partial-result store of gatmi_gat_fwd_noalloc (the entry point for callers that may not allocate):
+// a fixed array inside the code object instead of a caller workspace.  Every GPU the library runs
+// on holds its own copy at its own address until the process ends.  In host code the NAME below is
+// only a handle for hipGetSymbolAddress; kernels always receive the per-device address it returns.
+constexpr size_t kScratchFloats = GATMI_NOALLOC_SCRATCH_BYTES / sizeof(float);
+static __device__ __align__(256) float scratch[kScratchFloats];
 
 struct FwdArgs {
     const int4 *items;
@@ -36,6 +44,7 @@ struct FwdArgs {
     const void *feat;          // gathered source rows, fp32 or bf16 (template parameter BF16)
     const float *f1, *f2, *bias, *resid;
     float *out, *agg, *pos, *lse, *q, *ws;
+    int64_t ws_slots;          // partial-result records `ws` has room for (pieces beyond it are dropped, never written)
     int activation, reduce;
     float slope, coef_keep, feat_keep;
     uint64_t seed;
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
 
     if (item.w < 0) {
         fwd_finish<G, LPH, SAVE>(st, a, row, sub, head);
-    } else {
+    } else if (item.w < a.ws_slots) {
         // piece of a long row: park the un-normalised state; layout [m H | s H | q H | acc HD | pos HD]
         float *rec = a.ws + (int64_t)item.w * (3 * H + 2 * HD);
         if (sub % LPH == 0) {
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(256) void gat_fwd_merge_kernel(FwdArgs a, const int
     st.q = 0.f;
     st.acc = make_float4(0.f, 0.f, 0.f, 0.f);
     st.pos = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < rec.z; ++c) {
+    for (int c = 0; c < rec.z && rec.y + c < a.ws_slots; ++c) {
         const float *p = a.ws + (int64_t)(rec.y + c) * (3 * H + 2 * HD);
         const float pm = p[head], ps = p[H + head], pq = p[2 * H + head];
         const float4 pa = *reinterpret_cast<const float4 *>(p + 3 * H + sub * 4);
@@ -575,6 +584,48 @@ extern "C" size_t gatmi_gat_fwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp
     return (size_t)n_slots * (size_t)(3 * H + 2 * H * dp);
 }
 
+static int gat_fwd_impl(const char *name, int64_t n_dst, int32_t H, int32_t dp,
+                        const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
+                        const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
+                        const float *bias, const float *resid, int32_t activation, int32_t reduce,
+                        float slope, float coef_keep, float feat_keep, uint64_t seed,
+                        float *out, float *agg, float *pos, float *lse, float *q,
+                        float *ws, int64_t ws_slots, void *stream) {
+    int G, LPH;
+    int rc = check_shape(H, dp, &G, &LPH);
+    if (rc) return rc;
+    GATMI_REQUIRE(n_dst >= 0 && n_items >= 0 && n_split >= 0, GATMI_EINVAL, "%s: negative size", name);
+    if (n_dst == 0 || n_items == 0) return GATMI_OK;
+    GATMI_REQUIRE(items && feat && f1 && f2 && out, GATMI_EINVAL, "%s: null pointer", name);
+    GATMI_REQUIRE(n_items >= n_dst, GATMI_EINVAL, "%s: %lld work items for %lld rows (every row needs an item)", name, (long long)n_items, (long long)n_dst);
+    GATMI_REQUIRE(n_split == 0 || (split && ws), GATMI_EINVAL, "%s: split rows need `split` and a partial-result store", name);
+    GATMI_REQUIRE(act_known(activation), GATMI_EUNSUPPORTED, "%s: activation %d", name, activation);
+    GATMI_REQUIRE(reduce == GATMI_REDUCE_CONCAT || (reduce == GATMI_REDUCE_MEAN && activation == GATMI_ACT_IDENTITY), GATMI_EUNSUPPORTED,
+                  "%s: reduce %d with activation %d (mean over heads needs the identity activation)", name, reduce, activation);
+    GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "%s: keep probabilities must be in (0,1]", name);
+    const bool save = agg || pos || lse || q;
+    GATMI_REQUIRE(!save || (agg && pos && lse && q), GATMI_EINVAL, "%s: agg, pos, lse, q must be given together", name);
+    GATMI_REQUIRE_ALIGNED(items); GATMI_REQUIRE_ALIGNED(split); GATMI_REQUIRE_ALIGNED(feat); GATMI_REQUIRE_ALIGNED(bias);
+    GATMI_REQUIRE_ALIGNED(resid); GATMI_REQUIRE_ALIGNED(out); GATMI_REQUIRE_ALIGNED(agg); GATMI_REQUIRE_ALIGNED(pos); GATMI_REQUIRE_ALIGNED(ws);
+    FwdArgs a;
+    a.items = reinterpret_cast<const int4 *>(items);
+    a.n_items = n_items;
+    a.col = col; a.feat = feat; a.f1 = f1; a.f2 = f2; a.bias = bias; a.resid = resid;
+    a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.ws = ws; a.ws_slots = ws_slots;
+    a.activation = activation; a.reduce = reduce;
+    a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
+    const bool drop = coef_keep < 1.f || feat_keep < 1.f;
+    GATMI_REQUIRE(feat_dtype == GATMI_DTYPE_F32 || feat_dtype == GATMI_DTYPE_BF16, GATMI_EUNSUPPORTED, "%s: feat_dtype %d", name, feat_dtype);
+    const bool bf16 = feat_dtype == GATMI_DTYPE_BF16;
+    GATMI_REQUIRE(!(bf16 && drop), GATMI_EUNSUPPORTED, "%s: dropout is only built for fp32 source rows", name);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int4 *sp = reinterpret_cast<const int4 *>(split);
+#define X(g, l) if (G == g && LPH == l) return launch_fwd<g, l>(a, sp, n_split, save, drop, bf16, st);
+    GATMI_FOR_SHAPES(X)
+#undef X
+    return fail(GATMI_EUNSUPPORTED, "%s: no kernel for H=%d dp=%d", name, H, dp);
+}
+
 extern "C" int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
                              const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                              const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
@@ -582,39 +633,57 @@ extern "C" int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
                              float slope, float coef_keep, float feat_keep, uint64_t seed,
                              float *out, float *agg, float *pos, float *lse, float *q,
                              float *ws, void *stream) {
-    int G, LPH;
-    int rc = check_shape(H, dp, &G, &LPH);
-    if (rc) return rc;
-    GATMI_REQUIRE(n_dst >= 0 && n_items >= 0 && n_split >= 0, GATMI_EINVAL, "gat_fwd: negative size");
-    if (n_dst == 0 || n_items == 0) return GATMI_OK;
-    GATMI_REQUIRE(items && feat && f1 && f2 && out, GATMI_EINVAL, "gat_fwd: null pointer");
-    GATMI_REQUIRE(n_items >= n_dst, GATMI_EINVAL, "gat_fwd: %lld work items for %lld rows (every row needs an item)", (long long)n_items, (long long)n_dst);
-    GATMI_REQUIRE(n_split == 0 || (split && ws), GATMI_EINVAL, "gat_fwd: split rows need `split` and `ws`");
-    GATMI_REQUIRE(act_known(activation), GATMI_EUNSUPPORTED, "gat_fwd: activation %d", activation);
-    GATMI_REQUIRE(reduce == GATMI_REDUCE_CONCAT || (reduce == GATMI_REDUCE_MEAN && activation == GATMI_ACT_IDENTITY), GATMI_EUNSUPPORTED,
-                  "gat_fwd: reduce %d with activation %d (mean over heads needs the identity activation)", reduce, activation);
-    GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "gat_fwd: keep probabilities must be in (0,1]");
-    const bool save = agg || pos || lse || q;
-    GATMI_REQUIRE(!save || (agg && pos && lse && q), GATMI_EINVAL, "gat_fwd: agg, pos, lse, q must be given together");
-    GATMI_REQUIRE_ALIGNED(items); GATMI_REQUIRE_ALIGNED(split); GATMI_REQUIRE_ALIGNED(feat); GATMI_REQUIRE_ALIGNED(bias);
-    GATMI_REQUIRE_ALIGNED(resid); GATMI_REQUIRE_ALIGNED(out); GATMI_REQUIRE_ALIGNED(agg); GATMI_REQUIRE_ALIGNED(pos); GATMI_REQUIRE_ALIGNED(ws);
-    FwdArgs a;
-    a.items = reinterpret_cast<const int4 *>(items);
-    a.n_items = n_items;
-    a.col = col; a.feat = feat; a.f1 = f1; a.f2 = f2; a.bias = bias; a.resid = resid;
-    a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.ws = ws;
-    a.activation = activation; a.reduce = reduce;
-    a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
-    const bool drop = coef_keep < 1.f || feat_keep < 1.f;
-    GATMI_REQUIRE(feat_dtype == GATMI_DTYPE_F32 || feat_dtype == GATMI_DTYPE_BF16, GATMI_EUNSUPPORTED, "gat_fwd: feat_dtype %d", feat_dtype);
-    const bool bf16 = feat_dtype == GATMI_DTYPE_BF16;
-    GATMI_REQUIRE(!(bf16 && drop), GATMI_EUNSUPPORTED, "gat_fwd: dropout is only built for fp32 source rows");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int4 *sp = reinterpret_cast<const int4 *>(split);
-#define X(g, l) if (G == g && LPH == l) return launch_fwd<g, l>(a, sp, n_split, save, drop, bf16, st);
-    GATMI_FOR_SHAPES(X)
-#undef X
-    return fail(GATMI_EUNSUPPORTED, "gat_fwd: no kernel for H=%d dp=%d", H, dp);
+    // the caller sized `ws` with gatmi_gat_fwd_ws_floats for its own slot count: no limit to enforce here
+    return gat_fwd_impl("gat_fwd", n_dst, H, dp, items, n_items, split, n_split, col, feat, feat_dtype, f1, f2, bias, resid,
+                        activation, reduce, slope, coef_keep, feat_keep, seed, out, agg, pos, lse, q, ws, INT64_MAX, stream);
+}
+
+// Address of this device's copy of `scratch`, looked up once per device with that device current.
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex scratch_mutex;
+float *scratch_of_device[kMaxDevices] = {};
+
+int scratch_for_current_device(float **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(GATMI_EHIP, "gat_fwd_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+    GATMI_REQUIRE(dev >= 0 && dev < kMaxDevices, GATMI_EUNSUPPORTED, "gat_fwd_noalloc: device ordinal %d (at most %d devices)", dev, kMaxDevices);
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (!scratch_of_device[dev]) {
+        float *p = nullptr;
+        e = hipGetSymbolAddress(reinterpret_cast<void **>(&p), HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return fail(GATMI_EHIP, "gat_fwd_noalloc: hipGetSymbolAddress on device %d: %s", dev, hipGetErrorString(e));
+        scratch_of_device[dev] = p;
+    }
+    *out = scratch_of_device[dev];
+    return GATMI_OK;
+}
+}  // namespace
+
+extern "C" int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
+                                     const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
+                                     int64_t n_slots,
+                                     const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
+                                     const float *bias, const float *resid, int32_t activation, int32_t reduce,
+                                     float slope, float coef_keep, float feat_keep, uint64_t seed,
+                                     float *out, float *agg, float *pos, float *lse, float *q, void *stream) {
+    GATMI_REQUIRE(n_slots >= 0 && (n_split == 0) == (n_slots == 0), GATMI_EINVAL,
+                  "gat_fwd_noalloc: n_slots=%lld with n_split=%lld (both come from gatmi_work_items_count)", (long long)n_slots, (long long)n_split);
+    const size_t need = gatmi_gat_fwd_ws_floats(n_slots, H, dp);
+    GATMI_REQUIRE(need <= kScratchFloats, GATMI_ERANGE,
+                  "gat_fwd_noalloc: %lld partial-result slots need %zu bytes, the built-in store holds %zu; use gatmi_gat_fwd "
+                  "with a workspace, or a larger chunk so that fewer rows are split", (long long)n_slots, need * sizeof(float), (size_t)GATMI_NOALLOC_SCRATCH_BYTES);
+    float *ws = nullptr;
+    if (n_slots > 0) {
+        int rc = scratch_for_current_device(&ws);
+        if (rc) return rc;
+    }
+    // Nothing in the store has to start at zero: each piece's record is written whole by the row kernel
+    // before the merge kernel, ordered behind it on `stream`, reads it.
+    return gat_fwd_impl("gat_fwd_noalloc", n_dst, H, dp, items, n_items, split, n_split, col, feat, feat_dtype, f1, f2, bias, resid,
+                        activation, reduce, slope, coef_keep, feat_keep, seed, out, agg, pos, lse, q, ws, n_slots, stream);
 }
 
 extern "C" size_t gatmi_gat_bwd_node_ws_floats(int32_t H, int32_t dp) { return (size_t)kNodeBlocks * (size_t)H * dp; }

@@ -183,6 +183,27 @@ int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
                   float *out, float *agg, float *pos, float *lse, float *q,
                   float *ws, void *stream);
 
+/* The same forward pass for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses with a no-allocation rule) and therefore cannot bring the
+ * workspace of gatmi_gat_fwd.  It has NO counterpart in the reference.  The partial results of split
+ * rows go to a fixed store of GATMI_NOALLOC_SCRATCH_BYTES inside the library's code object (one copy
+ * per GPU, held until the process ends) instead of `ws`; everything else, and every result bit, is as
+ * in gatmi_gat_fwd.  n_slots is the slot count gatmi_work_items_count reported for these items
+ * (0 when no row is split); the call fails with GATMI_ERANGE when
+ * gatmi_gat_fwd_ws_floats(n_slots, H, dp) * 4 exceeds the store (13 797 slots at H = 8, dp = 8).
+ * The function calls no hipMalloc / hipFree and no allocating routine.  Its first call on a device
+ * looks up that device's address of the store (hipGetSymbolAddress): make that first call outside
+ * stream capture.  All calls on one GPU share the store: calls that overlap in time on one GPU
+ * (different streams, or threads) race on it; calls ordered on one stream do not. */
+#define GATMI_NOALLOC_SCRATCH_BYTES (8u << 20)
+int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
+                          const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
+                          int64_t n_slots,
+                          const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
+                          const float *bias, const float *resid, int32_t activation, int32_t reduce,
+                          float slope, float coef_keep, float feat_keep, uint64_t seed,
+                          float *out, float *agg, float *pos, float *lse, float *q, void *stream);
+
 /* Backward, per-destination part (no gather).  From dOut and the saved forward tensors:
  *   g [n_dst, hd]    = dOut * activation'(out)              (dOut / H per head for mean);
  *       g16: the same rows in bf16 for gatmi_gat_bwd_csc's gather; either of g / g16 may be NULL
