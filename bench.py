@@ -9,7 +9,10 @@ ogbn-products shape, 2,449,029 nodes, 61,859,140 directed edges + one self-loop 
 100 input features, 8 heads x 8 hidden, ELU, fp32.  A step = forward + backward of the layer
 (all parameter gradients; no dX, it is a first layer), inputs resident in HBM, dropout off.
 For N > 1 every rank owns a products-sized block of destination rows of an N-times larger
-R-MAT graph (weak scaling) and exchanges halo rows with RCCL all-to-all.
+R-MAT graph (weak scaling) and exchanges halo rows with RCCL all-to-all (--halo exchange, the
+default: Wh / f2 rows forward, their gradients backward, every step, overlapped with the sweeps that
+do not need them).  --workload rmat2b gives every rank its share of BASELINE.json configs[4]
+(100 M nodes / 2 B edges over 8 GPUs: 12.5 M rows and 250 M edges + self-loops per rank).
 
 Prints ONE JSON line on rank 0.  `value` = directed edge entries (self-loops included)
 processed per second over all ranks.  `roofline` prices the slowest kernel of the step against
@@ -42,12 +45,18 @@ def parse():
     ap.add_argument("--edges", type=int, default=0, help="override edge count per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--workload", choices=["products", "cora"], default="products",
-                    help="products: the headline (default); cora: the two-layer Cora network, GPU vs the CPU restatement")
-    ap.add_argument("--halo", choices=["replicate", "exchange"], default="replicate",
-                    help="N > 1 only.  replicate (default): the layer is a first layer, its constant input rows of the halo "
-                         "sources are fetched once at set-up and projected locally, so a step communicates only the all-reduce "
-                         "of the parameter gradients; exchange: Wh / f2 rows and their gradients travel every step (RCCL all-to-all)")
+    ap.add_argument("--workload", choices=["products", "rmat2b", "cora"], default="products",
+                    help="products: the headline (default), per GPU the ogbn-products shape; rmat2b: per GPU one eighth of "
+                         "configs[4] (12.5 M rows, 250 M edges + self-loops: at --gpus 8 the 100 M-node / 2 B-edge graph); "
+                         "cora: the two-layer Cora network, GPU vs the CPU restatement")
+    ap.add_argument("--halo", choices=["exchange", "replicate", "both"], default="exchange",
+                    help="N > 1 only.  exchange (default, the measured configuration): Wh / f2 rows of the halo sources and "
+                         "their gradients travel every step (RCCL all-to-all); replicate: a first layer's constant input rows "
+                         "of the halo sources are fetched once at set-up and projected locally, a step communicates only the "
+                         "all-reduce of the parameter gradients; both: exchange is the line's value, the replicate-mode step "
+                         "is reported beside it under 'replicate_mode'")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1, exchange: run all-to-alls and kernels in turn instead of side by side")
     ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
                     help="bf16: gathered tables in bf16 (2e-2 parity class); the headline is f32")
     return ap.parse_args()
@@ -95,11 +104,38 @@ class EventProfiler:
         return timed
 
     def summary(self):
+        """name -> (mean milliseconds per call, number of calls)."""
         out = {}
         for name, evs in self.records.items():
             ms = [a.elapsed_time(b) for a, b in evs]
             out[name] = (sum(ms) / len(ms), len(ms))
         return out
+
+
+# kernel symbol each timed entry point launches at the benchmark's shape (8 heads x 8: 16 lanes per
+# row, 2 per head; training, no dropout), as rocprofv3 prints it: a PMC traffic figure is only
+# attached to the line when it was counted on a kernel of exactly this name
+KERNEL_SYMBOL = {
+    "gatmi_gat_fwd": {"f32": "gat_fwd_kernel<16, 2, true, false, false>", "bf16": "gat_fwd_kernel<16, 2, true, false, true>"},
+    "gatmi_gat_bwd_csc": {"f32": "gat_bwd_csc_kernel<16, 2, false, false>", "bf16": "gat_bwd_csc_kernel<16, 2, false, true>"},
+    "gatmi_gat_bwd_node": {"f32": "gat_bwd_node_kernel<16, 2>", "bf16": "gat_bwd_node_kernel<16, 2>"},
+}
+
+
+def pmc_traffic(entry, storage, E_rank):
+    """(bytes per launch, source) from profiles/traffic.json if it was taken on this workload and on the
+    kernel this run launched; (None, reason) otherwise."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return None, "profiles/traffic.json missing"
+    want = KERNEL_SYMBOL.get(entry, {}).get(storage)
+    have = tj.get("kernel_symbols", {}).get(entry)
+    if tj.get("workload_edges") != E_rank:
+        return None, "traffic.json is for another workload"
+    if want is None or have != want:
+        return None, "traffic.json counted %r, this run launched %r" % (have, want)
+    return tj["kernels"].get(entry), tj.get("source")
 
 
 def cpu_baseline(sample_nodes=272_114, sample_edges=6_873_238, iters=5):
@@ -192,6 +228,38 @@ def run_cora(args):
         flush=True)
 
 
+RMAT2B_NODES_PER_GPU = 12_500_000      # configs[4]: 100 M nodes / 2 B edges row-partitioned over 8 GPUs
+RMAT2B_EDGES_PER_GPU = 250_000_000
+
+
+def timed_steps(step, args, world, dev, lib):
+    """W warm-up steps, then K steps between two barrier + synchronize brackets, every C-ABI call
+    bracketed by HIP events.  Returns (seconds, max over ranks; per-entry-point summary)."""
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = EventProfiler()
+    raw_call = lib.call
+    lib.call = prof.wrap(raw_call)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.call = raw_call
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t[0])
+    return elapsed, prof.summary()
+
+
 def main():
     args = parse()
     if args.workload == "cora":
@@ -214,9 +282,18 @@ def main():
     from gat_amd import _lib, synth, CSRGraph
     from gat_amd.layers import GATHeads
 
-    n_own = args.nodes or synth.PRODUCTS_NODES
-    e_own = args.edges or synth.PRODUCTS_EDGES
+    if args.workload == "rmat2b":
+        n_own, e_own = RMAT2B_NODES_PER_GPU, RMAT2B_EDGES_PER_GPU
+        shape_name = "one eighth of the 100 M-node / 2 B-edge R-MAT graph per GPU"
+    else:
+        n_own, e_own = synth.PRODUCTS_NODES, synth.PRODUCTS_EDGES
+        shape_name = "R-MAT power-law graph at ogbn-products shape per GPU"
+    n_own = args.nodes or n_own
+    e_own = args.edges or e_own
     chunk = args.chunk
+    storage = args.storage
+    dist_info = None
+    replicate_line = None
 
     if world > 1:
         import torch.distributed as dist
@@ -225,7 +302,30 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-        layer_step, E_rank, info = gdist.build_bench_step(rank, world, n_own, e_own, F_IN, HEADS, WIDTH, dev, chunk, args.storage, args.halo)
+        bench = gdist.BenchShard(rank, world, n_own, e_own, F_IN, HEADS, WIDTH, dev, chunk, storage)
+        E_rank = bench.E_rank
+        info = bench.info()
+        modes = ["exchange", "replicate"] if args.halo == "both" else [args.halo]
+        results = {}
+        for mode in modes:
+            step = bench.step_fn(mode, overlap=not args.no_overlap)
+            bench.pg.exchange.enable_timing()
+            elapsed, ksum = timed_steps(step, args, world, dev, _lib)
+            torch.cuda.synchronize()
+            a2a_total_ms, sent, received, n_a2a = bench.pg.exchange.a2a_summary()
+            per_step = args.steps + args.warmup          # the exchange's events cover the warm-up steps too
+            results[mode] = (elapsed, ksum, {
+                "a2a_ms": round(a2a_total_ms / per_step, 4), "a2a_per_step": n_a2a // per_step,
+                "bytes_sent_per_step": sent // per_step, "bytes_received_per_step": received // per_step})
+            bench.release(mode)
+        elapsed, ksum, comm = results[modes[0]]
+        dist_info = dict(comm, backend=("rccl" if backend == "nccl" else backend), world_size=dist.get_world_size(),
+                         halo=modes[0], overlap=(modes[0] == "exchange" and not args.no_overlap),
+                         n_halo=bench.pg.n_halo, n_send=bench.pg.exchange.n_send,
+                         local_entry_fraction=round(bench.pg.local_entries / max(1, E_rank), 4))
+        if len(modes) == 2:
+            e2, k2, c2 = results["replicate"]
+            replicate_line = (e2, k2, c2)
     else:
         dst, src = synth.rmat_graph(n_own, e_own, 4, dev)
         graph = CSRGraph.from_device_coo(dst, src, n_own, n_own, chunk=chunk)
@@ -233,7 +333,7 @@ def main():
         E_rank = graph.nnz
         x = synth.normal((n_own, F_IN), 5, dev)
         dout = synth.normal((n_own, HEADS * WIDTH), 8, dev)
-        heads = GATHeads(F_IN, HEADS, WIDTH, device=dev, storage=args.storage)
+        heads = GATHeads(F_IN, HEADS, WIDTH, device=dev, storage=storage)
         heads.load(synth.glorot_layer(F_IN, HEADS, WIDTH, 7, dev))
         heads.train()
         params = list(heads.parameters())
@@ -244,75 +344,69 @@ def main():
                 p.grad = None
             out = heads(x, graph, "elu", "concat")
             out.backward(dout)
+        elapsed, ksum = timed_steps(layer_step, args, world, dev, _lib)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        layer_step()
-    prof = EventProfiler()
-    raw_call = _lib.call
-    _lib.call = prof.wrap(raw_call)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        layer_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    _lib.call = raw_call
-
-    t = torch.tensor([elapsed, float(E_rank)], dtype=torch.float64, device=dev)
+    E_total = float(E_rank)
     if world > 1:
-        tmax = t.clone()
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        t = torch.tensor([float(E_rank)], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
-        elapsed, E_total = float(tmax[0]), float(t[1])
-    else:
-        E_total = float(E_rank)
+        E_total = float(t[0])
     ms_per_step = elapsed / args.steps * 1e3
 
     if rank == 0:
-        ksum = prof.summary()
-        dom = max(ksum, key=lambda k: ksum[k][0]) if ksum else None
+        s_bytes = 4 if storage == "f32" else 2
+        per_step = {k: v[0] * v[1] / args.steps for k, v in ksum.items()}       # ms per step of each entry point (all its launches)
+        dom = max(per_step, key=per_step.get) if per_step else None
         roofline = None
         if dom:
-            ab = kernel_alg_bytes(dom, E_rank, n_own, s=4 if args.storage == "f32" else 2)
-            gbps = ab / (ksum[dom][0] * 1e-3) / 1e9
-            traffic, traffic_src = None, None
-            try:   # PMC-measured HBM bytes per launch, taken in separate rocprofv3 --pmc runs of this same workload
-                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                if world == 1 and args.storage == "f32" and tj.get("workload_edges") == E_rank:
-                    traffic, traffic_src = tj["kernels"].get(dom), tj.get("source")
-            except (OSError, ValueError, KeyError):
-                pass
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            ab = kernel_alg_bytes(dom, E_rank, n_own, s=s_bytes)
+            gbps = ab / (per_step[dom] * 1e-3) / 1e9
+            traffic, traffic_src = (None, "single-GPU figure only") if world > 1 else pmc_traffic(dom, storage, E_rank)
+            roofline = {"bound": "hbm", "kernel": dom, "kernel_symbol": KERNEL_SYMBOL.get(dom, {}).get(storage),
+                        "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "alg_bytes_per_launch": ab, "avg_ms": round(ksum[dom][0], 4)}
-        lb = layer_alg_bytes(E_rank, n_own, s=4 if args.storage == "f32" else 2)
+                        "alg_bytes_per_launch": ab, "avg_ms": round(per_step[dom], 4),
+                        "launches_per_step": ksum[dom][1] // args.steps}
+        lb = layer_alg_bytes(E_rank, n_own, s=s_bytes)
         lg = lb / (ms_per_step * 1e-3) / 1e9
+        impl = sum(kernel_alg_bytes(k, E_rank, n_own, s=s_bytes) for k in
+                   ("gatmi_proj_fwd", "gatmi_gat_fwd", "gatmi_gat_bwd_node", "gatmi_gat_bwd_csc", "gatmi_proj_bwd_params"))
+        ig = impl / (ms_per_step * 1e-3) / 1e9
+        if world == 1:
+            partitioning = "single GPU"
+        elif dist_info["halo"] == "replicate":
+            partitioning = ("row-partitioned x%d, halo sources' input rows replicated at set-up and projected locally; per step one "
+                            "RCCL all-reduce of the parameter gradients" % world)
+        else:
+            partitioning = ("row-partitioned x%d, RCCL all-to-all of halo Wh/f2 rows (forward) and of their gradients (backward) every "
+                            "step%s, one all-reduce of the parameter gradients"
+                            % (world, "" if args.no_overlap else ", on a communication stream beside the sweeps over owned sources / owned columns"))
         line = {
             "metric": "GAT layer fwd+bwd edges/sec (8 heads) + % HBM roofline at 1/2/4/8 GPUs",
             "value": E_total / (ms_per_step * 1e-3), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.storage == "f32" else "f32 arithmetic, bf16 gather tables", "data": "synthetic",
-            "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
-            "config": {"workload": "R-MAT power-law graph at ogbn-products shape per GPU: %d nodes, %d edge entries "
-                                   "(self-loops included), %d-d features, %d heads x %d, ELU, fwd+bwd of one layer"
-                                   % (n_own, E_rank, F_IN, HEADS, WIDTH),
-                       "partitioning": "single GPU" if world == 1 else (
-                           "row-partitioned x%d, " % world + (
-                               "halo sources' input rows replicated at set-up and projected locally; per step one RCCL "
-                               "all-reduce of the parameter gradients" if args.halo == "replicate" else
-                               "RCCL all-to-all of halo Wh/f2 rows (forward) and of their gradients (backward) every step"))},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if storage == "f32" else "f32 arithmetic, bf16 gather tables", "data": "synthetic",
+            "backend": dist_info["backend"] if dist_info else None,
+            "config": {"workload": "%s: %d nodes, %d edge entries (self-loops included), %d-d features, %d heads x %d, ELU, "
+                                   "fwd+bwd of one layer" % (shape_name, n_own, E_rank, F_IN, HEADS, WIDTH),
+                       "name": args.workload, "partitioning": partitioning},
             "roofline": roofline,
             "layer_roofline": {"bound": "hbm", "alg_bytes": lb, "achieved": round(lg, 1), "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": round(lg / HBM_PEAK_GBPS, 4)},
-            "kernels_ms": {k: round(v[0], 4) for k, v in sorted(ksum.items())},
+                               "unit": "GB/s", "frac": round(lg / HBM_PEAK_GBPS, 4),
+                               "note": "survey byte model (944 B/edge + 2984 B/node), the common yardstick; impl_* prices the bytes "
+                                       "this implementation's five kernels actually have to move",
+                               "impl_bytes": impl, "impl_achieved": round(ig, 1), "impl_frac": round(ig / HBM_PEAK_GBPS, 4)},
+            "kernels_ms": {k: round(v, 4) for k, v in sorted(per_step.items())},
             "info": info,
         }
+        if dist_info:
+            line["dist"] = dist_info
+        if replicate_line:
+            e2, k2, c2 = replicate_line
+            ms2 = e2 / args.steps * 1e3
+            line["replicate_mode"] = dict(c2, ms_per_step=round(ms2, 4), value=E_total / (ms2 * 1e-3),
+                                          kernels_ms={k: round(v[0] * v[1] / args.steps, 4) for k, v in sorted(k2.items())})
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

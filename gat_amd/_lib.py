@@ -33,6 +33,8 @@ _SIGNATURES = {
     "gatmi_csc_from_csr": (c_int, [c_int64, c_int64, P, P, P, P, P]),
     "gatmi_work_items_count": (c_int, [c_int64, P, c_int32, P, P, P]),
     "gatmi_work_items": (c_int, [c_int64, P, c_int32, P, P]),
+    "gatmi_work_items_phased_count": (c_int, [c_int64, P, P, c_int32, P, P, P, P]),
+    "gatmi_work_items_phased": (c_int, [c_int64, P, P, c_int32, P, P, P]),
     "gatmi_partition_rows": (c_int, [c_int64, c_int32, P, c_int32, P]),
     "gatmi_halo_plan": (c_int, [c_int32, c_int32, P, c_int64, P, P, P, P, P]),
     "gatmi_proj_fwd": (c_int, [P, c_int64, c_int32, c_int64, P, P, P, P, P, c_int32, c_int32, P, P, P, P, P, P, P]),
@@ -71,6 +73,7 @@ _SIGNATURES = {
     "gatmi_ipd_bwd": (c_int, [c_int64, c_int32, c_int32, P, P, P, c_int32, c_float, c_uint64, P, P]),
     "gatmi_halo_pack": (c_int, [P, P, c_int64, c_int32, P, P]),
     "gatmi_halo_unpack_add": (c_int, [P, P, c_int64, c_int32, P, P]),
+    "gatmi_halo_unpack_sum": (c_int, [P, P, P, P, c_int64, c_int32, P, P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

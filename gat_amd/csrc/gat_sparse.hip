@@ -172,6 +172,16 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
     st.q = 0.f;
     st.acc = make_float4(0.f, 0.f, 0.f, 0.f);
     st.pos = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (item.w <= -2 && (int64_t)(-item.w - 2) < a.ws_slots) {
+        // second phase of a row whose first entries were swept by an earlier launch (two-phase work
+        // items of a row-partitioned shard): take up the state that launch parked, then finish the row
+        const float *rec = a.ws + (int64_t)(-item.w - 2) * (3 * H + 2 * HD);
+        st.m = rec[head];
+        st.s = rec[H + head];
+        st.q = rec[2 * H + head];
+        st.acc = *reinterpret_cast<const float4 *>(rec + 3 * H + sub * 4);
+        st.pos = *reinterpret_cast<const float4 *>(rec + 3 * H + HD + sub * 4);
+    }
     int k = 0;
     for (; k + 4 <= len; k += 4) fwd_batch<G, LPH, 4, SAVE, DROP, BF16>(st, a, cp + k, (int64_t)item.y + k, f1v, sub, head);
     if (k + 2 <= len) {
@@ -597,7 +607,6 @@ static int gat_fwd_impl(const char *name, int64_t n_dst, int32_t H, int32_t dp,
     GATMI_REQUIRE(n_dst >= 0 && n_items >= 0 && n_split >= 0, GATMI_EINVAL, "%s: negative size", name);
     if (n_dst == 0 || n_items == 0) return GATMI_OK;
     GATMI_REQUIRE(items && feat && f1 && f2 && out, GATMI_EINVAL, "%s: null pointer", name);
-    GATMI_REQUIRE(n_items >= n_dst, GATMI_EINVAL, "%s: %lld work items for %lld rows (every row needs an item)", name, (long long)n_items, (long long)n_dst);
     GATMI_REQUIRE(n_split == 0 || (split && ws), GATMI_EINVAL, "%s: split rows need `split` and a partial-result store", name);
     GATMI_REQUIRE(act_known(activation), GATMI_EUNSUPPORTED, "%s: activation %d", name, activation);
     GATMI_REQUIRE(reduce == GATMI_REDUCE_CONCAT || (reduce == GATMI_REDUCE_MEAN && activation == GATMI_ACT_IDENTITY), GATMI_EUNSUPPORTED,
@@ -732,7 +741,6 @@ extern "C" int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
     GATMI_REQUIRE(n_src >= 0 && n_items >= 0 && n_split >= 0, GATMI_EINVAL, "gat_bwd_csc: negative size");
     if (n_src == 0 || n_items == 0) return GATMI_OK;
     GATMI_REQUIRE(items && g && stats && feat && f2 && dfeat && df2, GATMI_EINVAL, "gat_bwd_csc: null pointer");
-    GATMI_REQUIRE(n_items >= n_src, GATMI_EINVAL, "gat_bwd_csc: %lld work items for %lld rows", (long long)n_items, (long long)n_src);
     GATMI_REQUIRE((a1 == nullptr) == (a2 == nullptr) && (!a1 || df1), GATMI_EINVAL, "gat_bwd_csc: a1, a2 and df1 go together");
     GATMI_REQUIRE(n_split == 0 || (split && ws), GATMI_EINVAL, "gat_bwd_csc: split rows need `split` and `ws`");
     GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "gat_bwd_csc: keep probabilities must be in (0,1]");

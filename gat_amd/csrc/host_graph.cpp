@@ -181,6 +181,107 @@ extern "C" int gatmi_work_items(int64_t n, const int64_t *ptr, int32_t chunk,
     return GATMI_OK;
 }
 
+// ---- two-phase work items (row-partitioned shards) ---------------------------------------------
+namespace {
+struct PhasedCount { int64_t a = 0, b = 0, split = 0, slots = 0; };
+
+inline int64_t pieces_or_none(int64_t len, int64_t chunk) { return len <= 0 ? 0 : pieces_of(len, chunk); }
+
+int phased_count(int64_t n, const int64_t *ptr, const int64_t *cut, int32_t chunk, PhasedCount *c) {
+    GATMI_REQUIRE(n >= 0 && ptr && cut && chunk > 0, GATMI_EINVAL, "work_items_phased: bad arguments");
+    GATMI_REQUIRE(ptr[n] < INT32_MAX && n < INT32_MAX, GATMI_ERANGE, "work_items_phased: %lld entries do not fit int32 offsets", (long long)ptr[n]);
+    for (int64_t i = 0; i < n; ++i) {
+        if (cut[i] < ptr[i] || cut[i] > ptr[i + 1])
+            return fail(GATMI_EINVAL, "work_items_phased: cut[%lld]=%lld outside its row [%lld,%lld]", (long long)i, (long long)cut[i], (long long)ptr[i], (long long)ptr[i + 1]);
+        int64_t pa = pieces_or_none(cut[i] - ptr[i], chunk), pb = pieces_or_none(ptr[i + 1] - cut[i], chunk);
+        if (pa + pb == 0) pa = 1;                       // an empty row still writes its output
+        c->a += pa;
+        c->b += pb;
+        if (pa == 1 && pb == 1) c->slots += 1;          // parked by phase A, resumed by phase B
+        else if (pa + pb > 1) { c->split++; c->slots += pa + pb; }
+    }
+    return GATMI_OK;
+}
+
+// positions of the pieces of one phase in its list: longest first, stable by (row, piece)
+struct LengthOrder {
+    std::vector<int64_t> pos;
+    explicit LengthOrder(int32_t chunk) : pos(chunk + 2, 0) {}
+    void count(int64_t len, int64_t chunk) {
+        if (len <= chunk) pos[len]++;
+        else {
+            int64_t p = pieces_of(len, chunk);
+            pos[chunk] += p - 1;
+            pos[len - (p - 1) * chunk]++;
+        }
+    }
+    void finish(int64_t chunk) {
+        int64_t acc = 0;
+        for (int64_t l = chunk; l >= 0; --l) { int64_t c = pos[l]; pos[l] = acc; acc += c; }
+    }
+};
+}  // namespace
+
+extern "C" int gatmi_work_items_phased_count(int64_t n, const int64_t *ptr, const int64_t *cut, int32_t chunk,
+                                             int64_t *n_a_out, int64_t *n_b_out, int64_t *n_split_out, int64_t *n_slots_out) {
+    GATMI_REQUIRE(n_a_out && n_b_out && n_split_out && n_slots_out, GATMI_EINVAL, "work_items_phased_count: null output");
+    PhasedCount c;
+    int rc = phased_count(n, ptr, cut, chunk, &c);
+    if (rc) return rc;
+    *n_a_out = c.a; *n_b_out = c.b; *n_split_out = c.split; *n_slots_out = c.slots;
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_work_items_phased(int64_t n, const int64_t *ptr, const int64_t *cut, int32_t chunk,
+                                       int32_t *items_a_out, int32_t *items_b_out, int32_t *split_out) {
+    PhasedCount c;
+    int rc = phased_count(n, ptr, cut, chunk, &c);
+    if (rc) return rc;
+    GATMI_REQUIRE((items_a_out || c.a == 0) && (items_b_out || c.b == 0) && (split_out || c.split == 0), GATMI_EINVAL, "work_items_phased: null output");
+    LengthOrder oa(chunk), ob(chunk);
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t la = cut[i] - ptr[i], lb = ptr[i + 1] - cut[i];
+        if (la > 0 || lb == 0) oa.count(la, chunk);
+        if (lb > 0) ob.count(lb, chunk);
+    }
+    oa.finish(chunk);
+    ob.finish(chunk);
+    int64_t slot = 0, s = 0;
+    auto emit = [&](int32_t *out, LengthOrder &o, int64_t row, int64_t first, int64_t len, int64_t w) {
+        int32_t *it = out + 4 * o.pos[len]++;
+        it[0] = (int32_t)row; it[1] = (int32_t)first; it[2] = (int32_t)len; it[3] = (int32_t)w;
+    };
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t la = cut[i] - ptr[i], lb = ptr[i + 1] - cut[i];
+        int64_t pa = pieces_or_none(la, chunk), pb = pieces_or_none(lb, chunk);
+        if (pa + pb == 0) pa = 1;
+        if (pa + pb == 1) {
+            if (pa) emit(items_a_out, oa, i, ptr[i], la, -1);
+            else emit(items_b_out, ob, i, cut[i], lb, -1);
+        } else if (pa == 1 && pb == 1) {
+            emit(items_a_out, oa, i, ptr[i], la, slot);
+            emit(items_b_out, ob, i, cut[i], lb, -(slot + 2));
+            slot += 1;
+        } else {
+            split_out[4 * s + 0] = (int32_t)i;
+            split_out[4 * s + 1] = (int32_t)slot;
+            split_out[4 * s + 2] = (int32_t)(pa + pb);
+            split_out[4 * s + 3] = 0;
+            ++s;
+            for (int64_t k = 0; k < pa; ++k) {
+                const int64_t b = ptr[i] + k * chunk;
+                emit(items_a_out, oa, i, b, std::min<int64_t>(chunk, cut[i] - b), slot + k);
+            }
+            for (int64_t k = 0; k < pb; ++k) {
+                const int64_t b = cut[i] + k * chunk;
+                emit(items_b_out, ob, i, b, std::min<int64_t>(chunk, ptr[i + 1] - b), slot + pa + k);
+            }
+            slot += pa + pb;
+        }
+    }
+    return GATMI_OK;
+}
+
 extern "C" int gatmi_partition_rows(int64_t n, int32_t nparts, const int64_t *rowptr, int32_t balance,
                                     int64_t *part_out) {
     GATMI_REQUIRE(n >= 0 && nparts > 0 && part_out, GATMI_EINVAL, "partition_rows: bad arguments");

@@ -6,11 +6,14 @@ out_i needs only {Wh_j, f2_j : j in N(i)} (utils/layers.py:16-24).  Rank p owns 
 of destination rows, their X rows and their CSR rows.  Sources owned by other ranks ("halo") are
 listed once per (owner, requester) pair, sorted by global id, and appended after the owned rows:
 
-  forward   K1 on owned rows -> pack rows peers asked for -> all-to-all(v) of Wh and f2 rows ->
-            fused edge-softmax + aggregation over owned + halo source rows
-  backward  per-destination kernel on owned rows -> per-source kernel over owned + halo rows ->
-            reverse all-to-all(v) of the halo rows' dWh / df2 contributions -> add at the owner ->
-            finish owned rows -> parameter gradients on owned rows (+ one small all-reduce)
+  forward   K1 on owned rows -> pack rows peers asked for -> all-to-all(v) of Wh and f2 rows on a
+            communication stream WHILE the aggregation kernel sweeps the entries whose sources are
+            owned -> second sweep over the entries that read halo rows, taking up each row's parked
+            softmax state (two-phase work items, gatmi_work_items_phased)
+  backward  per-destination kernel on owned rows -> per-source kernel over the HALO columns ->
+            reverse all-to-all(v) of their dWh / df2 contributions WHILE the per-source kernel does
+            the owned columns -> one launch adds every peer's rows at the owner -> finish owned
+            rows -> parameter gradients on owned rows (+ one small all-reduce)
 
 For a FIRST layer the exchange can be traded for memory: its input X is constant over training and
 needs no gradient, so every rank fetches the X rows of its halo sources once (`replicate_rows`) and
@@ -79,9 +82,25 @@ def _pack_rows(table, idx, n_idx, width, out):
     _lib.call("gatmi_halo_pack", ptr(table), ptr(idx), n_idx, width, ptr(out), _lib.current_stream())
 
 
-def _unpack_add_rows(rows, idx, n_idx, width, table):
-    """table[idx[k]] += rows[k] on the current HIP stream (gatmi_halo_unpack_add)."""
-    _lib.call("gatmi_halo_unpack_add", ptr(rows), ptr(idx), n_idx, width, ptr(table), _lib.current_stream())
+def _unpack_sum_rows(recv, plan, width, table):
+    """table[rows[u]] += sum of recv[pos[k]] over each row's list, all peers in one launch, fixed order
+    (gatmi_halo_unpack_sum).  plan = (rows, ptr, pos) int64 tensors from HaloExchange."""
+    rows, rptr, pos = plan
+    _lib.call("gatmi_halo_unpack_sum", ptr(recv), ptr(rows), ptr(rptr), ptr(pos), rows.numel(), width, ptr(table),
+              _lib.current_stream())
+
+
+class _Pending:
+    """An exchange in flight on the communication stream: wait() orders the current stream behind it."""
+
+    def __init__(self, event=None, keep=None):
+        self.event, self.keep = event, keep
+
+    def wait(self):
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+        keep, self.keep, self.event = self.keep, None, None
+        return keep
 
 
 class HaloExchange:
@@ -109,6 +128,63 @@ class HaloExchange:
             self.send_counts = [0] * world
             self.send_idx = torch.empty(0, dtype=torch.int64, device=self.device)
         self.n_send = int(self.send_idx.numel())
+        # the send list inverted: for every owned row some peer reads, where its returned copies sit in
+        # the receive buffer of the reverse exchange (rows sorted, copies in peer order)
+        order = torch.argsort(self.send_idx, stable=True)
+        rows, counts = torch.unique_consecutive(self.send_idx[order], return_counts=True)
+        rptr = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=self.device)
+        rptr[1:] = torch.cumsum(counts, 0)
+        self.unpack_plan = (rows.contiguous(), rptr, order.contiguous())
+        self._comm_stream = None
+        self.timings = None          # list of (start event, end event, bytes sent, bytes received) when enabled
+
+    def enable_timing(self):
+        """Bracket every all-to-all with HIP events on the communication stream (bench.py)."""
+        self.timings = []
+
+    def a2a_summary(self):
+        """(total milliseconds, bytes sent, bytes received, number of all-to-alls) recorded since
+        enable_timing(); the events must have completed (synchronise first)."""
+        if not self.timings:
+            return 0.0, 0, 0, 0
+        return (sum(a.elapsed_time(b) for a, b, _, _ in self.timings), sum(t[2] for t in self.timings),
+                sum(t[3] for t in self.timings), len(self.timings))
+
+    def _comm(self):
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(self.device)
+        return self._comm_stream
+
+    def _mark(self, pairs):
+        """Event on the current stream behind which the exchange of `pairs` may start (None for host buffers)."""
+        if not pairs or not pairs[0][1].is_cuda:
+            return None
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        return ready
+
+    def _exchange(self, pairs, out_splits, in_splits, ready):
+        """All-to-all of every (out, inp) pair.  Device buffers: issued on the communication stream
+        behind `ready`, so kernels enqueued on the current stream after `ready` was recorded run beside
+        it; returns a _Pending to wait on.  Host buffers: done on return."""
+        if ready is None:
+            for out, inp in pairs:
+                self._a2a(out, inp, out_splits, in_splits)
+            return _Pending()
+        cs = self._comm()
+        cs.wait_event(ready)
+        with torch.cuda.stream(cs):
+            for out, inp in pairs:
+                if self.timings is not None:
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record(cs)
+                self._a2a(out, inp, out_splits, in_splits)
+                if self.timings is not None:
+                    t1.record(cs)
+                    self.timings.append((t0, t1, inp.numel() * inp.element_size(), out.numel() * out.element_size()))
+            done = torch.cuda.Event()
+            done.record(cs)
+        return _Pending(done, [t for pr in pairs for t in pr])
 
     def _a2a(self, out, inp, out_splits, in_splits):
         """all_to_all_single (every rank calls it, also with nothing to send); buffers are staged
@@ -124,26 +200,67 @@ class HaloExchange:
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
+    def gather_halo_pack(self, tables):
+        """tables: list of (table [n_own + n_halo, width], width) whose owned rows are valid.  Packs the
+        rows the peers asked for (current stream) and returns a ticket for gather_halo_start.  Kernels
+        launched between the two calls run beside the exchange."""
+        if self.world == 1:
+            return None
+        pairs = []
+        for table, width in tables:
+            send = torch.empty((self.n_send, width), dtype=table.dtype, device=table.device)
+            if self.n_send:
+                _pack_rows(table, self.send_idx, self.n_send, width, send)
+            pairs.append((table[self.n_own:], send))
+        return pairs, self._mark(pairs)
+
+    def gather_halo_start(self, ticket):
+        """Starts the all-to-all(v) that fills the halo rows; returns a _Pending.  Until its wait()
+        nothing may read the halo rows."""
+        if ticket is None:
+            return _Pending()
+        pairs, ready = ticket
+        return self._exchange(pairs, self.recv_counts, self.send_counts, ready)
+
     def gather_halo(self, table, width):
         """table [n_own + n_halo, width]: owned rows valid; fills the halo rows from their owners."""
+        self.gather_halo_start(self.gather_halo_pack([(table, width)])).wait()
+
+    def scatter_add_halo_mark(self, tables):
+        """Reverse direction, step 1: the halo rows of every (table, width) are final as of now on the
+        current stream (they must not change until scatter_add_halo_finish); returns a ticket."""
+        if self.world == 1:
+            return None
+        pairs = []
+        for table, width in tables:
+            recv = torch.empty((self.n_send, width), dtype=table.dtype, device=table.device)
+            pairs.append((recv, table[self.n_own:]))
+        return pairs, self._mark(pairs)
+
+    def scatter_add_halo_start(self, ticket):
+        """Step 2: starts the all-to-all(v) that carries those rows back to their owners."""
+        if ticket is None:
+            return _Pending()
+        pairs, ready = ticket
+        pend = self._exchange(pairs, self.send_counts, self.recv_counts, ready)
+        pend.recvs = [r for r, _ in pairs]
+        return pend
+
+    def scatter_add_halo_finish(self, pend, tables):
+        """Step 3: waits for the reverse exchange and adds the returned rows to the owned rows (one
+        launch per table for all peers, fixed summation order)."""
         if self.world == 1:
             return
-        send = torch.empty((self.n_send, width), dtype=table.dtype, device=table.device)
-        if self.n_send:
-            _pack_rows(table, self.send_idx, self.n_send, width, send)
-        self._a2a(table[self.n_own:], send, self.recv_counts, self.send_counts)
+        recvs = pend.recvs
+        pend.wait()
+        for (table, width), recv in zip(tables, recvs):
+            if self.n_send:
+                _unpack_sum_rows(recv, self.unpack_plan, width, table)
 
     def scatter_add_halo(self, table, width):
-        """Reverse: halo rows of table go back to their owners and are added to the owned rows."""
-        if self.world == 1:
-            return
-        recv = torch.empty((self.n_send, width), dtype=table.dtype, device=table.device)
-        self._a2a(recv, table[self.n_own:].contiguous(), self.send_counts, self.recv_counts)
-        off = 0
-        for c in self.send_counts:          # one launch per peer: inside a peer's list rows are distinct
-            if c:
-                _unpack_add_rows(recv[off:], self.send_idx[off:], c, width, table)
-            off += c
+        """Halo rows of table go back to their owners and are added to the owned rows."""
+        tables = [(table, width)]
+        self.scatter_add_halo_finish(self.scatter_add_halo_start(self.scatter_add_halo_mark(tables)), tables)
 
 
 class PartitionedGraph:
@@ -152,6 +269,39 @@ class PartitionedGraph:
     def __init__(self, graph, exchange, part, rank):
         self.graph, self.exchange, self.part, self.rank = graph, exchange, np.asarray(part), rank
         self.n_own, self.n_halo = exchange.n_own, exchange.n_halo
+        self._phase_lists()
+
+    def _phase_lists(self):
+        """Work lists that let the exchanges run beside the kernels.  Forward: every CSR row keeps its
+        owned sources first (rows are sorted by local id, halo ids follow the owned ones), so the row is
+        cut there: phase A = entries reading owned rows, phase B = entries reading halo rows
+        (gatmi_work_items_phased).  Backward: the per-source items are divided into halo columns (swept
+        first: their results travel) and owned columns (swept while those travel)."""
+        g, dev = self.graph, self.graph.device
+        n = g.n_dst
+        rowptr = g.rowptr_host
+        if g.nnz:
+            c = torch.zeros(g.nnz + 1, dtype=torch.int64, device=dev)
+            c[1:] = torch.cumsum(g.col < self.n_own, 0, dtype=torch.int64)
+            rp = torch.from_numpy(rowptr).to(dev)
+            cut = (rp[:-1] + c[rp[1:]] - c[rp[:-1]]).cpu().numpy()
+            del c, rp
+        else:
+            cut = rowptr[:-1].copy()
+        cut = np.ascontiguousarray(cut, dtype=np.int64)
+        na, nb, ns, nl = (ctypes.c_int64() for _ in range(4))
+        _lib.call("gatmi_work_items_phased_count", n, ptr(rowptr), ptr(cut), g.chunk, ctypes.byref(na), ctypes.byref(nb),
+                  ctypes.byref(ns), ctypes.byref(nl))
+        ia, ib = np.empty((na.value, 4), dtype=np.int32), np.empty((nb.value, 4), dtype=np.int32)
+        sp = np.empty((ns.value, 4), dtype=np.int32)
+        _lib.call("gatmi_work_items_phased", n, ptr(rowptr), ptr(cut), g.chunk, ptr(ia), ptr(ib), ptr(sp))
+        to = lambda a: torch.from_numpy(a).to(dev)
+        self.items_a, self.items_b, self.split_ab, self.n_slots_ab = to(ia), to(ib), to(sp), nl.value
+        self.local_entries = int((cut - rowptr[:-1]).sum())
+        own = g.items_csc[:, 0] < self.n_own
+        self.items_csc_own, self.items_csc_halo = g.items_csc[own].contiguous(), g.items_csc[~own].contiguous()
+        own = g.split_csc[:, 0] < self.n_own
+        self.split_csc_own, self.split_csc_halo = g.split_csc[own].contiguous(), g.split_csc[~own].contiguous()
 
     @classmethod
     def from_global_csr(cls, rowptr, col, part, rank, world, device, chunk=DEFAULT_CHUNK, group=None):
@@ -195,7 +345,7 @@ class DistSparseGATLayerFn(torch.autograd.Function):
     """SparseGATLayerFn with the halo exchange between the projection and the aggregation."""
 
     @staticmethod
-    def forward(ctx, x, W, a1, a2, b1, b2, bias, pgraph, cfg, replicate=False):
+    def forward(ctx, x, W, a1, a2, b1, b2, bias, pgraph, cfg, replicate=False, overlap=True):
         ops._require_cuda(x, W)
         x = ops._f32(x).contiguous()
         graph, ex = pgraph.graph, pgraph.exchange
@@ -224,21 +374,14 @@ class DistSparseGATLayerFn(torch.autograd.Function):
                   ptr(b2.contiguous()), H, dp, ptr(feat), ptr(f1), ptr(f2), None, None, None, st)
         bf16 = cfg.storage == "bf16"
         gtab, gdt = feat, _lib.DTYPE_F32
-        if replicate:
-            if bf16:
-                gtab, gdt = torch.empty((n_src, hd), dtype=torch.bfloat16, device=x.device), _lib.DTYPE_BF16
-                _lib.call("gatmi_to_bf16", ptr(feat), n_src * hd, ptr(gtab), st)
-        elif bf16:
+        if bf16:
             # bf16 mode: the gathered table and therefore the halo rows on the wire are bf16 (half the
-            # forward exchange); the owned fp32 rows stay for the parameter gradients
+            # forward exchange); the fp32 rows stay for the backward sweep and the parameter gradients
             gtab, gdt = torch.empty((n_src, hd), dtype=torch.bfloat16, device=x.device), _lib.DTYPE_BF16
-            _lib.call("gatmi_to_bf16", ptr(feat), n * hd, ptr(gtab), st)
-            ex.gather_halo(gtab.view(torch.float32), hd // 2)
-            feat[n:].copy_(gtab[n:])        # the per-source backward sweep reads its own Wh row in fp32 (exact widening)
-        else:
-            ex.gather_halo(feat, hd)
+            _lib.call("gatmi_to_bf16", ptr(feat), n_proj * hd, ptr(gtab), st)
+        ticket = None
         if not replicate:
-            ex.gather_halo(f2, H)
+            ticket = ex.gather_halo_pack([(gtab.view(torch.float32), hd // 2) if bf16 else (feat, hd), (f2, H)])
         biasp = None if bias is None else ops._pad_last(bias.reshape(H, D), D, dp).reshape(hd)
         need_grad = any(ctx.needs_input_grad)
         out = ops._new((n, dp if cfg.reduce == "mean" else hd), x)
@@ -246,16 +389,31 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         if need_grad:
             agg, pos = ops._new((n, hd), x), ops._new((n, hd), x)
             lse, q = ops._new((n, H), x), ops._new((n, H), x)
-        ws = None
-        if len(graph.split_csr):
-            ws = ops._new((_lib.lib.gatmi_gat_fwd_ws_floats(graph.n_slots_csr, H, dp),), x)
-        _lib.call("gatmi_gat_fwd", n, H, dp, ptr(graph.items_csr), len(graph.items_csr),
-                  ptr(graph.split_csr) if len(graph.split_csr) else None, len(graph.split_csr),
-                  ptr(graph.col), ptr(gtab), gdt, ptr(f1), ptr(f2), ptr(biasp), None,
-                  ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
-                  ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
+
+        def sweep(items, split, ws):
+            _lib.call("gatmi_gat_fwd", n, H, dp, ptr(items), len(items), ptr(split) if len(split) else None, len(split),
+                      ptr(graph.col), ptr(gtab), gdt, ptr(f1), ptr(f2), ptr(biasp), None,
+                      ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
+                      ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
+        two_phase = ticket is not None and overlap and len(pgraph.items_a) and len(pgraph.items_b)
+        if two_phase:
+            ws = ops._new((max(1, _lib.lib.gatmi_gat_fwd_ws_floats(pgraph.n_slots_ab, H, dp)),), x)
+            sweep(pgraph.items_a, pgraph.split_ab[:0], ws)       # entries reading owned rows, beside the exchange
+            ex.gather_halo_start(ticket).wait()
+            if bf16:
+                feat[n:].copy_(gtab[n:])        # the per-source backward sweep reads its own Wh row in fp32 (exact widening)
+            sweep(pgraph.items_b, pgraph.split_ab, ws)           # entries reading halo rows; merges rows cut further
+        else:
+            if ticket is not None:
+                ex.gather_halo_start(ticket).wait()
+                if bf16:
+                    feat[n:].copy_(gtab[n:])
+            ws = None
+            if len(graph.split_csr):
+                ws = ops._new((_lib.lib.gatmi_gat_fwd_ws_floats(graph.n_slots_csr, H, dp),), x)
+            sweep(graph.items_csr, graph.split_csr, ws)
         if need_grad:
-            ctx.pgraph, ctx.cfg, ctx.has_bias, ctx.replicate = pgraph, cfg, bias is not None, replicate
+            ctx.pgraph, ctx.cfg, ctx.has_bias, ctx.replicate, ctx.overlap = pgraph, cfg, bias is not None, replicate, overlap
             ctx.save_for_backward(x, Wp, a1p, a2p, feat, f1, f2, out, agg, pos, lse, q)
         if cfg.reduce == "mean":
             return out[:, :D] if D != dp else out
@@ -293,35 +451,48 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         ws2 = None
         if len(graph.split_csc):
             ws2 = ops._new((_lib.lib.gatmi_gat_bwd_ws_floats(graph.n_slots_csc, H, dp),), x)
-        _lib.call("gatmi_gat_bwd_csc", n_src, H, dp, ptr(graph.items_csc), len(graph.items_csc),
-                  ptr(graph.split_csc) if len(graph.split_csc) else None, len(graph.split_csc),
-                  ptr(graph.rowidx), ptr(graph.perm), ptr(g16 if bf16 else g), _lib.DTYPE_BF16 if bf16 else _lib.DTYPE_F32,
-                  ptr(stats), ptr(feat), ptr(f2), ptr(df1) if replicate else None, ptr(a1p) if replicate else None,
-                  ptr(a2p) if replicate else None,
-                  cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dfeat), ptr(df2), ptr(ws2), st)
+
+        def sweep(items, split):
+            if len(items) == 0:
+                return
+            _lib.call("gatmi_gat_bwd_csc", n_src, H, dp, ptr(items), len(items), ptr(split) if len(split) else None, len(split),
+                      ptr(graph.rowidx), ptr(graph.perm), ptr(g16 if bf16 else g), _lib.DTYPE_BF16 if bf16 else _lib.DTYPE_F32,
+                      ptr(stats), ptr(feat), ptr(f2), ptr(df1) if replicate else None, ptr(a1p) if replicate else None,
+                      ptr(a2p) if replicate else None,
+                      cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dfeat), ptr(df2), ptr(ws2), st)
         if replicate:
+            sweep(graph.items_csc, graph.split_csc)
             # dfeat already holds dWh (the logit terms df1.a1 + df2.a2 were added by the sweep): this rank's
             # share of every sum over sources, on owned + halo rows; the all-reduce of the parameter
             # gradients adds the shares of the other ranks
             _, dW, da1, da2, db1, db2, _ = ops._project_backward(x, Wp, None, feat, dfeat, df1, df2, g, cfg, False)
             db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None
-            return None, dW, da1, da2, db1, db2, db, None, None, None
-        ex.scatter_add_halo(dfeat, hd)
-        ex.scatter_add_halo(df2, H)
+            return None, dW, da1, da2, db1, db2, db, None, None, None, None
+        tables = [(dfeat, hd), (df2, H)]
+        if ctx.overlap and ex.world > 1:
+            sweep(pgraph.items_csc_halo, pgraph.split_csc_halo)      # the columns whose results travel
+            ticket = ex.scatter_add_halo_mark(tables)
+            sweep(pgraph.items_csc_own, pgraph.split_csc_own)        # owned columns, beside the exchange
+        else:
+            sweep(graph.items_csc, graph.split_csc)
+            ticket = ex.scatter_add_halo_mark(tables)
+        ex.scatter_add_halo_finish(ex.scatter_add_halo_start(ticket), tables)
         _lib.call("gatmi_gat_bwd_finalize", n, H, dp, ptr(df1), ptr(df2), ptr(a1p), ptr(a2p), ptr(dfeat), st)
         dWh = dfeat[:n]
         dx, dW, da1, da2, db1, db2, _ = ops._project_backward(x, Wp, None, feat, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
         db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None
-        return dx, dW, da1, da2, db1, db2, db, None, None, None
+        return dx, dW, da1, da2, db1, db2, db, None, None, None, None
 
 
-def dist_sparse_gat_layer(x, W, a1, a2, b1, b2, bias, pgraph, cfg, halo="exchange"):
-    """halo="exchange": x [n_own, F], Wh / f2 rows of halo sources travel every step (any layer).
+def dist_sparse_gat_layer(x, W, a1, a2, b1, b2, bias, pgraph, cfg, halo="exchange", overlap=True):
+    """halo="exchange": x [n_own, F], Wh / f2 rows of halo sources travel every step (any layer);
+    overlap=True runs the all-to-alls on a communication stream beside the sweeps that do not need
+    them (same results up to summation order), overlap=False runs exchange and kernels in turn.
     halo="replicate": x [n_own + n_halo, F] from pgraph.replicate_rows (constant first-layer input):
     no communication besides the all-reduce of the parameter gradients."""
     if halo not in ("exchange", "replicate"):
         raise ValueError("halo must be 'exchange' or 'replicate'")
-    return DistSparseGATLayerFn.apply(x, W, a1, a2, b1, b2, bias, pgraph, cfg, halo == "replicate")
+    return DistSparseGATLayerFn.apply(x, W, a1, a2, b1, b2, bias, pgraph, cfg, halo == "replicate", bool(overlap))
 
 
 def allreduce_grads(params, group=None):
@@ -342,33 +513,51 @@ def allreduce_grads(params, group=None):
         off += g.numel()
 
 
-def build_bench_step(rank, world, n_own, e_own, f_in, heads, width, device, chunk=DEFAULT_CHUNK, storage="f32",
-                     halo="replicate"):
+class BenchShard:
     """bench.py's N > 1 workload: every rank owns n_own destination rows of an R-MAT graph with
-    world * n_own nodes and generates its own e_own in-edges (sources over the whole id range)."""
-    from . import synth
-    from .layers import GATHeads
-    n_global = n_own * world
-    part = np.arange(world + 1, dtype=np.int64) * n_own
-    dst, src = synth.rmat_graph(n_global, e_own, 4 + 1000 * rank, device, row_range=(int(part[rank]), int(part[rank + 1])))
-    pg = PartitionedGraph.from_device_edges(dst, src, part, rank, world, chunk)
-    del dst, src
-    x = synth.normal((n_own, f_in), 5 + 1000 * rank, device)
-    if halo == "replicate":
-        x = pg.replicate_rows(x)            # set-up, outside the timed step: the input features are constant
-    dout = synth.normal((n_own, heads * width), 8 + 1000 * rank, device)
-    m = GATHeads(f_in, heads, width, device=device)
-    m.load(synth.glorot_layer(f_in, heads, width, 7, device))
-    m.train()
-    params = list(m.parameters())
-    cfg = ops.make_cfg(heads, width, "elu", "concat", storage=storage)
+    world * n_own nodes and generates its own e_own in-edges (sources over the whole id range, node
+    labels scrambled so that the hubs spread over all owners)."""
 
-    def step():
-        for p in params:
-            p.grad = None
-        out = dist_sparse_gat_layer(x, m.W, m.a1, m.a2, m.b1, m.b2, m.bias, pg, cfg, halo)
-        out.backward(dout)
-        allreduce_grads(params)
+    def __init__(self, rank, world, n_own, e_own, f_in, heads, width, device, chunk=DEFAULT_CHUNK, storage="f32"):
+        from . import synth
+        from .layers import GATHeads
+        self.rank, self.world, self.device = rank, world, device
+        part = np.arange(world + 1, dtype=np.int64) * n_own
+        dst, src = synth.rmat_graph(n_own * world, e_own, 4 + 1000 * rank, device, row_range=(int(part[rank]), int(part[rank + 1])))
+        self.pg = PartitionedGraph.from_device_edges(dst, src, part, rank, world, chunk)
+        del dst, src
+        self.E_rank = self.pg.graph.nnz
+        self.x = synth.normal((n_own, f_in), 5 + 1000 * rank, device)
+        self.x_rep = None
+        self.dout = synth.normal((n_own, heads * width), 8 + 1000 * rank, device)
+        self.m = GATHeads(f_in, heads, width, device=device)
+        self.m.load(synth.glorot_layer(f_in, heads, width, 7, device))
+        self.m.train()
+        self.cfg = ops.make_cfg(heads, width, "elu", "concat", storage=storage)
 
-    info = {"graph": repr(pg.graph), "n_halo": pg.n_halo, "n_send": pg.exchange.n_send, "halo": halo}
-    return step, pg.graph.nnz, info
+    def info(self):
+        pg = self.pg
+        return {"graph": repr(pg.graph), "n_halo": pg.n_halo, "n_send": pg.exchange.n_send,
+                "two_phase_items": [len(pg.items_a), len(pg.items_b), len(pg.split_ab), pg.n_slots_ab]}
+
+    def step_fn(self, halo, overlap=True):
+        m, pg, cfg, dout = self.m, self.pg, self.cfg, self.dout
+        params = list(m.parameters())
+        if halo == "replicate":
+            if self.x_rep is None:
+                self.x_rep = pg.replicate_rows(self.x)       # set-up, outside the timed steps: the input features are constant
+            x = self.x_rep
+        else:
+            x = self.x
+
+        def step():
+            for p in params:
+                p.grad = None
+            out = dist_sparse_gat_layer(x, m.W, m.a1, m.a2, m.b1, m.b2, m.bias, pg, cfg, halo, overlap)
+            out.backward(dout)
+            allreduce_grads(params)
+        return step
+
+    def release(self, halo):
+        if halo == "replicate":
+            self.x_rep = None

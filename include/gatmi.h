@@ -91,6 +91,24 @@ int gatmi_work_items_count(int64_t n, const int64_t *ptr, int32_t chunk,
 int gatmi_work_items(int64_t n, const int64_t *ptr, int32_t chunk,
                      int32_t *items_out, int32_t *split_out);
 
+/* Two-phase work items for a row-partitioned shard whose rows keep their owned sources first:
+ * entries [ptr[i], cut[i]) of row i read rows this GPU owns, [cut[i], ptr[i+1]) read halo rows that
+ * arrive from peers.  items_a cover the first parts (they can be swept while the halo rows are still
+ * in flight), items_b the second parts; both lists are ordered longest first.  The last field of an
+ * item says what happens to the row's running softmax state after the piece:
+ *     -1        the row is finished and written (all its entries were in this piece);
+ *     s >= 0    the state is parked in partial-result slot s;
+ *     -(s + 2)  the state parked in slot s is taken up first, then the row is finished.
+ * A row with one piece in each phase uses the third form (one slot, no merge); rows with more pieces
+ * (longer than `chunk` on either side) park every piece and get a split record {row, first_slot,
+ * n_slots, 0} for the merge step of gatmi_gat_fwd.  Run gatmi_gat_fwd with items_a and n_split = 0,
+ * then, once the halo rows have arrived, with items_b and the split list, both with the same `ws`
+ * of gatmi_gat_fwd_ws_floats(n_slots, H, dp) floats. */
+int gatmi_work_items_phased_count(int64_t n, const int64_t *ptr, const int64_t *cut, int32_t chunk,
+                                  int64_t *n_a_out, int64_t *n_b_out, int64_t *n_split_out, int64_t *n_slots_out);
+int gatmi_work_items_phased(int64_t n, const int64_t *ptr, const int64_t *cut, int32_t chunk,
+                            int32_t *items_a_out, int32_t *items_b_out, int32_t *split_out);
+
 /* Contiguous 1-D row partition into nparts blocks: part_out[nparts+1], part p owns rows
  * [part_out[p], part_out[p+1]).  balance = 0: equal row counts; 1: equal stored-entry counts. */
 int gatmi_partition_rows(int64_t n, int32_t nparts, const int64_t *rowptr, int32_t balance,
@@ -162,7 +180,9 @@ int gatmi_proj_bwd_params_csr(const int64_t *xt_rowptr, const int32_t *xt_row, c
  * (logits, LeakyReLU, additive mask, softmax), :20 (coefficient dropout), :22 (feature dropout),
  * :24 (coefs . seq_fts), :25 (bias_add), :30 (residual add), :34 (activation) and the head
  * concat / mean of models/sp_gat.py:17,32 — for all H heads.
- *   items/n_items, split/n_split : gatmi_work_items of the CSR rowptr; col: CSR source ids
+ *   items/n_items, split/n_split : gatmi_work_items of the CSR rowptr (or a sub-list of them: only
+ *       the rows named by the items are computed and written; the merge step runs for the rows in
+ *       `split`; see gatmi_work_items_phased for the item encoding); col: CSR source ids
  *   feat [n_src, hd] gathered rows (Wh) stored as feat_dtype (GATMI_DTYPE_F32, or GATMI_DTYPE_BF16
  *       written by gatmi_to_bf16: dropout must then be off); f1 [n_dst, H]; f2 [n_src, H]
  *   bias [hd] or NULL; resid [n_dst, hd] or NULL (per head, added before the activation; with
@@ -335,6 +355,14 @@ int gatmi_halo_pack(const float *src, const int64_t *idx, int64_t n_idx, int32_t
                     float *dst, void *stream);
 int gatmi_halo_unpack_add(const float *src, const int64_t *idx, int64_t n_idx, int32_t width,
                           float *dst, void *stream);
+
+/* All peers' returned rows in ONE launch: for u < n_rows, dst[rows[u], :] += src[pos[k], :] summed over
+ * k in [ptr[u], ptr[u+1]) in list order.  rows = the distinct owned rows that peers read, pos = for each
+ * of them the positions of its copies in the receive buffer (the send list inverted).  A target row
+ * belongs to one thread group, so rows returned by several peers need neither atomics nor one launch per
+ * peer, and the sum has a fixed order. */
+int gatmi_halo_unpack_sum(const float *src, const int64_t *rows, const int64_t *ptr, const int64_t *pos,
+                          int64_t n_rows, int32_t width, float *dst, void *stream);
 
 #ifdef __cplusplus
 }

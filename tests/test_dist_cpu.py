@@ -1,5 +1,6 @@
 """world_size-2 rehearsal of the row-partitioned layer on CPU (gloo): partition, halo plan,
-send-list handshake, forward halo gather and reverse scatter-add.  The HIP pack / unpack kernels
+send-list handshake, forward halo gather and reverse scatter-add (the send list inverted into one
+summation plan for all peers).  The HIP pack / unpack kernels
 cannot run without a GPU, so this test swaps them for torch index ops (stand-ins that exist only
 here) and runs the oracle's math on each rank's shard: the partitioned result must equal the
 single-graph oracle result, forward and backward — with the per-step exchange of projected rows and
@@ -20,8 +21,9 @@ def _cpu_pack(table, idx, n_idx, width, out):
     out.copy_(table[idx[:n_idx]])
 
 
-def _cpu_unpack_add(rows, idx, n_idx, width, table):
-    table.index_add_(0, idx[:n_idx], rows[:n_idx])
+def _cpu_unpack_sum(recv, plan, width, table):
+    rows, rptr, pos = plan
+    table.index_add_(0, torch.repeat_interleave(rows, rptr[1:] - rptr[:-1]), recv[pos])
 
 
 def _worker(rank, world, port, n, seed, q):
@@ -32,7 +34,7 @@ def _worker(rank, world, port, n, seed, q):
         from gat_amd import dist as gdist, graph
         from oracle import ref_numpy, ref_torch
         from tests.util import layer_params, random_graph
-        gdist._pack_rows, gdist._unpack_add_rows = _cpu_pack, _cpu_unpack_add
+        gdist._pack_rows, gdist._unpack_sum_rows = _cpu_pack, _cpu_unpack_sum
 
         F, H, D = 7, 2, 4
         dst, src = random_graph(n, 4.0, seed, hubs=2, hub_deg=n // 2)

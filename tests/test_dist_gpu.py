@@ -52,6 +52,16 @@ def _worker(rank, world, port, q):
         assert_close(xd.grad.cpu().numpy(), xs.grad.cpu().numpy()[lo:hi], rtol=1e-5, atol_scale=2e-6, what="dX")
         for k in p:
             assert_close(dp_[k].grad.cpu().numpy(), tp[k].grad.cpu().numpy(), rtol=1e-5, atol_scale=5e-6, what="d" + k)
+        # the same without overlap (exchange and kernels in turn, one sweep per direction): same sums in another order
+        assert len(pg.items_a) and len(pg.items_b) and pg.n_slots_ab > 0 and len(pg.items_csc_halo) >= pg.n_halo > 0
+        s_ = leaves()
+        xq = torch.tensor(x[lo:hi], device=dev, requires_grad=True)
+        oseq = gdist.dist_sparse_gat_layer(xq, s_["W"], s_["a1"], s_["a2"], s_["b1"], s_["b2"], s_["bias"], pg, cfg, overlap=False)
+        oseq.backward(torch.tensor(dout[lo:hi], device=dev))
+        gdist.allreduce_grads(list(s_.values()))
+        assert_close(oseq.detach().cpu().numpy(), out.detach().cpu().numpy(), rtol=2e-6, atol_scale=1e-6, what="overlap vs sequential out")
+        assert_close(xq.grad.cpu().numpy(), xd.grad.cpu().numpy(), rtol=1e-5, atol_scale=2e-6, what="overlap vs sequential dX")
+        assert_close(s_["W"].grad.cpu().numpy(), dp_["W"].grad.cpu().numpy(), rtol=1e-5, atol_scale=5e-6, what="overlap vs sequential dW")
         # first-layer mode: halo sources' input rows replicated once, no exchange inside the step
         r_ = leaves()
         xr = pg.replicate_rows(torch.tensor(x[lo:hi], device=dev))

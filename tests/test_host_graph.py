@@ -166,3 +166,66 @@ def test_sparse_features_index_preparation():
     assert (f.t_val.numpy() == t.data).all()
     assert f.t_rowptr.dtype == torch.int64 and f.t_row.dtype == torch.int32
     assert (f.to_dense().numpy() == x.toarray()).all()
+
+
+@pytest.mark.parametrize("seed,chunk", [(0, 8), (1, 64), (2, 3)])
+def test_phased_work_items_cover_each_part_once_and_pair_their_slots(seed, chunk):
+    """gatmi_work_items_phased: rows cut at `cut` into a first part (phase A) and a second part
+    (phase B), each chunked; the last field of an item is -1 (finish), a slot (park), or -(slot+2)
+    (take up that slot, then finish); rows with more than one piece per phase get a split record."""
+    from gat_amd import _lib
+    from gat_amd._lib import ptr
+    UNSET = -2 ** 31
+    rng = np.random.default_rng(seed)
+    n = 300
+    lens = rng.integers(0, 40, n)
+    lens[rng.integers(0, n, 5)] = 0                         # empty rows
+    lens[rng.integers(0, n, 3)] = 500                       # rows far longer than the chunk
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    frac = rng.random(n)
+    frac[rng.integers(0, n, 30)] = 0.0                      # nothing in the first part
+    frac[rng.integers(0, n, 30)] = 1.0                      # nothing in the second part
+    cut = rowptr[:-1] + np.floor(frac * lens).astype(np.int64)
+    na, nb, ns, nl = (ctypes.c_int64() for _ in range(4))
+    _lib.call("gatmi_work_items_phased_count", n, ptr(rowptr), ptr(cut), chunk, ctypes.byref(na), ctypes.byref(nb),
+              ctypes.byref(ns), ctypes.byref(nl))
+    ia, ib = np.full((na.value, 4), UNSET, np.int32), np.full((nb.value, 4), UNSET, np.int32)
+    sp_ = np.full((ns.value, 4), UNSET, np.int32)
+    _lib.call("gatmi_work_items_phased", n, ptr(rowptr), ptr(cut), chunk, ptr(ia), ptr(ib), ptr(sp_))
+    assert (ia != UNSET).all() and (ib != UNSET).all() and (sp_ != UNSET).all()
+    for items in (ia, ib):
+        assert (np.diff(items[:, 2]) <= 0).all() and (items[:, 2] <= chunk).all()           # longest first
+    covered = np.zeros(int(rowptr[-1]), dtype=np.int32)
+    for items, phase in ((ia, 0), (ib, 1)):
+        for row, first, ln, w in items:
+            lo, hi = (rowptr[row], cut[row]) if phase == 0 else (cut[row], rowptr[row + 1])
+            assert lo <= first and first + ln <= hi, "piece outside its part"
+            covered[first:first + ln] += 1
+    assert (covered == 1).all()
+    slots_parked, slots_resumed, slot_row = set(), set(), {}
+    pieces = {}
+    for items in (ia, ib):
+        for row, first, ln, w in items:
+            pieces.setdefault(int(row), []).append(int(w))
+            if w >= 0:
+                assert w not in slots_parked
+                slots_parked.add(int(w)); slot_row[int(w)] = int(row)
+            elif w <= -2:
+                slots_resumed.add(int(-w - 2))
+    assert set(pieces) == set(range(n))                     # every row has an item, empty rows included
+    assert slots_parked == set(range(nl.value))
+    split_rows = {int(r[0]): (int(r[1]), int(r[2])) for r in sp_}
+    for row, ws in pieces.items():
+        if len(ws) == 1:
+            assert ws == [-1]
+        elif row in split_rows:
+            first, cnt = split_rows[row]
+            assert sorted(ws) == list(range(first, first + cnt))
+        else:
+            assert len(ws) == 2 and ws[0] >= 0 and ws[1] == -(ws[0] + 2) and slot_row[ws[0]] == row
+    assert all(s in slots_parked for s in slots_resumed)
+    bad = cut.copy()
+    bad[7] = rowptr[8] + 1
+    rc = _lib.lib.gatmi_work_items_phased_count(n, ptr(rowptr), ptr(bad), chunk, ctypes.byref(na), ctypes.byref(nb), ctypes.byref(ns), ctypes.byref(nl))
+    assert rc == -1 and "cut" in _lib.last_error()
