@@ -55,8 +55,12 @@ def parse():
                          "of the halo sources are fetched once at set-up and projected locally, a step communicates only the "
                          "all-reduce of the parameter gradients; both: exchange is the line's value, the replicate-mode step "
                          "is reported beside it under 'replicate_mode'")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="N > 1, exchange: run all-to-alls and kernels in turn instead of side by side")
+    ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
+                    help="N > 1, exchange: run the all-to-alls on a communication stream beside the sweeps that do not need "
+                         "them (on), or exchanges and kernels in turn (off).  The overlap costs some kernel time (every row's "
+                         "softmax state is parked between the two sweeps) and hides at most the sweep over owned sources, so "
+                         "which is faster depends on the share of owned sources and on the links: auto (default) times three "
+                         "steps of each at set-up, outside the timed region, and keeps the faster")
     ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
                     help="bf16: gathered tables in bf16 (2e-2 parity class); the headline is f32")
     return ap.parse_args()
@@ -307,8 +311,16 @@ def main():
         info = bench.info()
         modes = ["exchange", "replicate"] if args.halo == "both" else [args.halo]
         results = {}
+        overlap, overlap_trial = args.overlap == "on", None
+        if args.overlap == "auto" and "exchange" in modes:
+            trial = argparse.Namespace(warmup=2, steps=3)
+            overlap_trial = {}
+            for ov in (True, False):
+                t_ov, _ = timed_steps(bench.step_fn("exchange", overlap=ov), trial, world, dev, _lib)     # max over ranks: same choice everywhere
+                overlap_trial["on" if ov else "off"] = round(t_ov / trial.steps * 1e3, 4)
+            overlap = overlap_trial["on"] <= overlap_trial["off"]
         for mode in modes:
-            step = bench.step_fn(mode, overlap=not args.no_overlap)
+            step = bench.step_fn(mode, overlap=overlap)
             bench.pg.exchange.enable_timing()
             elapsed, ksum = timed_steps(step, args, world, dev, _lib)
             torch.cuda.synchronize()
@@ -320,7 +332,7 @@ def main():
             bench.release(mode)
         elapsed, ksum, comm = results[modes[0]]
         dist_info = dict(comm, backend=("rccl" if backend == "nccl" else backend), world_size=dist.get_world_size(),
-                         halo=modes[0], overlap=(modes[0] == "exchange" and not args.no_overlap),
+                         halo=modes[0], overlap=(modes[0] == "exchange" and overlap), overlap_trial_ms=overlap_trial,
                          n_halo=bench.pg.n_halo, n_send=bench.pg.exchange.n_send,
                          local_entry_fraction=round(bench.pg.local_entries / max(1, E_rank), 4))
         if len(modes) == 2:
@@ -380,7 +392,7 @@ def main():
         else:
             partitioning = ("row-partitioned x%d, RCCL all-to-all of halo Wh/f2 rows (forward) and of their gradients (backward) every "
                             "step%s, one all-reduce of the parameter gradients"
-                            % (world, "" if args.no_overlap else ", on a communication stream beside the sweeps over owned sources / owned columns"))
+                            % (world, ", on a communication stream beside the sweeps over owned sources / owned columns" if dist_info["overlap"] else ""))
         line = {
             "metric": "GAT layer fwd+bwd edges/sec (8 heads) + % HBM roofline at 1/2/4/8 GPUs",
             "value": E_total / (ms_per_step * 1e-3), "unit": "edges/s",

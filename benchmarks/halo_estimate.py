@@ -3,7 +3,12 @@
     backward exchange in halo="exchange" mode, and what it stores once in halo="replicate" mode;
   * the compute time of the step in replicate mode (owned + halo rows projected locally), measured
     in this one process with random rows standing in for the peers' input rows.  This is rank 0's
-    step without the all-reduce of the parameter gradients (a few KB)."""
+    step without the all-reduce of the parameter gradients (a few KB);
+  * the step in exchange mode with the peers emulated: every all-to-all is a device-to-device copy
+    of the same size on the communication stream (as many rows sent as received, random send list).
+    That prices everything of the exchange step except the links: pack, the two-phase forward sweep
+    (park and resume of each row's state), the split backward sweep and the one-launch unpack, with
+    and without the stream overlap."""
 import json
 import os
 import sys
@@ -28,6 +33,24 @@ class _NoPeers:
 
     def scatter_add_halo(self, table, width):
         pass
+
+
+class _LoopbackPeers(gdist.HaloExchange):
+    """HaloExchange whose peers are emulated on this GPU: as many rows leave as arrive, and an
+    all-to-all is a device-to-device copy of that size on the communication stream."""
+
+    def __init__(self, n_own, n_halo, device):
+        self.rank, self.world, self.group, self.backend = 0, 2, None, "loopback"
+        self.n_own, self.n_halo, self.device = n_own, n_halo, torch.device(device)
+        self.recv_counts, self.send_counts = [0, n_halo], [0, n_halo]
+        gen = torch.Generator(device=device)
+        gen.manual_seed(11)
+        reps = -(-n_halo // n_own)
+        self.send_idx = torch.cat([torch.randperm(n_own, device=device, generator=gen) for _ in range(reps)])[:n_halo].contiguous()
+        self._finish_setup()
+
+    def _a2a(self, out, inp, out_splits, in_splits):
+        out.copy_(inp)
 
 
 def main():
@@ -63,9 +86,29 @@ def main():
             step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 10 * 1e3
-        print(json.dumps({"world": world, "entries": g.nnz, "remote_entry_frac": round(remote, 3), "n_halo": n_halo,
-                          "exchange_MB_per_direction_f32": round(n_halo * 288 / 1e6), "replicated_input_MB": round(n_halo * F * 4 / 1e6),
-                          "replicate_step_ms": round(ms, 3), "edges_per_s_per_gpu": round(g.nnz / ms * 1e3)}), flush=True)
+        line = {"world": world, "entries": g.nnz, "remote_entry_frac": round(remote, 3), "n_halo": n_halo,
+                "exchange_MB_per_direction_f32": round(n_halo * 288 / 1e6), "replicated_input_MB": round(n_halo * F * 4 / 1e6),
+                "replicate_step_ms": round(ms, 3), "edges_per_s_per_gpu": round(g.nnz / ms * 1e3)}
+        if world > 1:
+            pe = gdist.PartitionedGraph(g, _LoopbackPeers(n_own, n_halo, dev), part, 0)
+            xo = x[:n_own].contiguous()
+            for overlap in (True, False):
+                def estep():
+                    for p in params:
+                        p.grad = None
+                    gdist.dist_sparse_gat_layer(xo, m.W, m.a1, m.a2, m.b1, m.b2, m.bias, pe, cfg, "exchange", overlap).backward(dout)
+                for _ in range(3):
+                    estep()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    estep()
+                torch.cuda.synchronize()
+                line["exchange_step_ms_links_emulated_%s" % ("overlap" if overlap else "sequential")] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
+            line["two_phase_items"] = [len(pe.items_a), len(pe.items_b), len(pe.split_ab), pe.n_slots_ab]
+            line["local_entry_frac"] = round(pe.local_entries / g.nnz, 3)
+            del pe, xo
+        print(json.dumps(line), flush=True)
         del g, pg, x, dout, m
 
 

@@ -127,6 +127,9 @@ class HaloExchange:
         else:
             self.send_counts = [0] * world
             self.send_idx = torch.empty(0, dtype=torch.int64, device=self.device)
+        self._finish_setup()
+
+    def _finish_setup(self):
         self.n_send = int(self.send_idx.numel())
         # the send list inverted: for every owned row some peer reads, where its returned copies sit in
         # the receive buffer of the reverse exchange (rows sorted, copies in peer order)

@@ -19,6 +19,50 @@ import torch
 from . import layers
 
 
+class TFAdam(torch.optim.Optimizer):
+    """tf.train.AdamOptimizer as the reference builds it (models/base_gattn.py:83: default beta1 = 0.9,
+    beta2 = 0.999, epsilon = 1e-8).  TensorFlow's update is
+        lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  var -= lr_t * m_t / (sqrt(v_t) + epsilon)
+    i.e. epsilon joins the UNcorrected second-moment root, whereas torch.optim.Adam adds it after the
+    bias correction (an epsilon sqrt(1 - beta2^t) times smaller in TensorFlow's terms: 32 times at the
+    first step).  For gradients of the size an L2 penalty alone produces the two take visibly
+    different steps, so the drop-in keeps TensorFlow's form."""
+
+    def __init__(self, params, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-8):
+        super().__init__(params, dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["t"], st["m"], st["v"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+            t = self.state[ps[0]]["t"] + 1
+            for p in ps:
+                self.state[p]["t"] = t
+            b1, b2 = group["beta1"], group["beta2"]
+            lr_t = group["lr"] * (1.0 - b2 ** t) ** 0.5 / (1.0 - b1 ** t)
+            gs = [p.grad for p in ps]
+            ms = [self.state[p]["m"] for p in ps]
+            vs = [self.state[p]["v"] for p in ps]
+            torch._foreach_mul_(ms, b1)
+            torch._foreach_add_(ms, gs, alpha=1.0 - b1)
+            torch._foreach_mul_(vs, b2)
+            torch._foreach_addcmul_(vs, gs, gs, value=1.0 - b2)
+            den = torch._foreach_sqrt(vs)
+            torch._foreach_add_(den, group["eps"])
+            torch._foreach_addcdiv_(ps, ms, den, value=-lr_t)
+        return loss
+
+
 class BaseGAttN:
     """Loss / metric / optimiser helpers of models/base_gattn.py."""
 
@@ -130,7 +174,7 @@ class BaseGAttN:
         builds an exponential-decay schedule (:82) but never passes global_step to minimize (:86),
         so the step counter stays 0 and the rate never decays."""
         parameters = list(parameters)
-        opt = torch.optim.Adam(parameters, lr=lr, betas=(0.9, 0.999), eps=1e-8)
+        opt = TFAdam(parameters, lr=lr)
         return opt, (lambda: BaseGAttN.l2_penalty(parameters, l2_coef))
 
 
