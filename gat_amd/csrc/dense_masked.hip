@@ -61,11 +61,12 @@ struct MRowState {
 #endif
 constexpr int kBatch = GATMI_MASK_BATCH;  // list entries per step of a row / column walk (independent gathers in flight)
 
-// ids[t] = t-th of kBatch consecutive uint16 list entries at lp (16-byte aligned)
-__device__ __forceinline__ void load_ids(const uint16_t *lp, int (&ids)[kBatch]) {
-    static_assert(kBatch == 4 || kBatch == 8, "four or eight 16-bit ids per step");
+// ids[t] = t-th of NB consecutive uint16 list entries at lp (16-byte aligned for 8, 8-byte for 4)
+template <int NB>
+__device__ __forceinline__ void load_ids(const uint16_t *lp, int (&ids)[NB]) {
+    static_assert(NB == 4 || NB == 8, "four or eight 16-bit ids per step");
     uint32_t w[4];
-    if constexpr (kBatch == 8) {
+    if constexpr (NB == 8) {
         const uint4 packed = *reinterpret_cast<const uint4 *>(lp);
         w[0] = packed.x; w[1] = packed.y; w[2] = packed.z; w[3] = packed.w;
     } else {
@@ -73,7 +74,7 @@ __device__ __forceinline__ void load_ids(const uint16_t *lp, int (&ids)[kBatch])
         w[0] = packed.x; w[1] = packed.y; w[2] = w[3] = 0;
     }
 #pragma unroll
-    for (int t = 0; t < kBatch; ++t) ids[t] = (w[t >> 1] >> (16 * (t & 1))) & 0xffff;
+    for (int t = 0; t < NB; ++t) ids[t] = (w[t >> 1] >> (16 * (t & 1))) & 0xffff;
 }
 
 // One batch of up to kBatch listed sources of one destination row.
@@ -90,7 +91,7 @@ __device__ __forceinline__ void masked_fwd_batch(MRowState &st, const MaskedFwdA
     int j[U];
     float z[U], e[U];
     float4 v[U];
-    load_ids(lp, j);
+    load_ids<U>(lp, j);
 #pragma unroll
     for (int t = 0; t < U; ++t) {
         if (t >= nvalid) j[t] = j[0];
@@ -319,6 +320,250 @@ __global__ __launch_bounds__(256, GATMI_MASK_MINBLOCKS) void dense_masked_fwd_ke
     *reinterpret_cast<float4 *>(a.out + row * HD + sub * 4) = r;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// forward, graph-resident form: one block per graph, the graph's Wh rows and f2 values staged in
+// LDS once, so the per-entry gathers of the list walk are LDS reads (256 B per clock and CU) instead
+// of L2 reads.  For batches of many small graphs (the block count is the batch size) whose rows are
+// a multiple of 16 bytes; the mask handling and the lists are those of the register-resident path of
+// dense_masked_fwd_kernel, and every wave walks row quads wave, wave + nwaves, ... on its own (no
+// block-wide barrier after the staging).
+// ------------------------------------------------------------------------------------------
+constexpr int kGraphBatch = 4;             // list entries per step of the LDS walks (short latency: four in flight suffice)
+constexpr int kGraphPadRows = 4;           // LDS rows after the graph's own: row N is the dummy row the list padding names
+
+// One batch of kGraphBatch listed sources of one destination row, gathered from LDS.  The lists are padded
+// to a whole batch with the id of a dummy row (Wh = 0, f2 = -inf: coefficient exactly 0), so no entry
+// needs a validity test.  SOFT: the visited entries of some row of the wave carry non-zero biases.
+template <int G, int LPH, bool SAVE, bool SOFT>
+__device__ __forceinline__ void graph_fwd_batch(MRowState &st, float slope, const uint16_t *lp, const float *bm, int N,
+                                                const float *whs, const float *f2s, float f1v) {
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    constexpr int U = kGraphBatch;
+    int j[U];
+    float z[U], e[U];
+    float4 v[U];
+    load_ids<U>(lp, j);
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        z[t] = f1v + f2s[j[t] * H];
+        v[t] = *reinterpret_cast<const float4 *>(whs + j[t] * HD);
+        if (SOFT) e[t] = bm[min(j[t], N - 1)];
+    }
+    float mn = st.m;
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        e[t] = SOFT ? leaky(z[t], slope) + e[t] : leaky(z[t], slope);
+        mn = fmaxf(mn, e[t]);
+    }
+    const float sc = exp_neg(st.m - mn);
+    float bs = 0.f, bq = 0.f;
+    float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f), bpos = bacc;
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        const float p = exp_neg(e[t] - mn);
+        bs += p;
+        bacc = f4_fma(p, v[t], bacc);
+        if (SAVE) {
+            const float pp = z[t] > 0.f ? p : 0.f;
+            bq += pp;
+            bpos = f4_fma(pp, v[t], bpos);
+        }
+    }
+    st.s = fmaf(st.s, sc, bs);
+    st.acc = f4_fma(sc, st.acc, bacc);
+    if (SAVE) {
+        st.q = fmaf(st.q, sc, bq);
+        st.pos = f4_fma(sc, st.pos, bpos);
+    }
+    st.m = mn;
+}
+
+constexpr int kGraphFwdThreads = 1024;
+constexpr size_t kGraphFwdLdsMax = 150 * 1024;
+
+// list capacity per row: every column, plus one batch of padding, as whole batches
+static inline int graph_list_capacity(int N) { return (N + 2 * kGraphBatch - 1) / kGraphBatch * kGraphBatch; }
+
+// LDS of the graph-resident forward kernel: Wh [N + pad][HD] | f2 [N + pad][H] | lists [waves][RPW][lc] (uint16)
+static inline size_t graph_fwd_lds(int N, int G, int H, int lc) {
+    return (size_t)(N + kGraphPadRows) * (4 * G + H) * sizeof(float) + (size_t)(kGraphFwdThreads / 64) * (64 / G) * lc * sizeof(uint16_t);
+}
+
+// Mask row of one lane group in registers: lane `sub` of the group holds columns 64k + 4 sub .. + 3 of
+// the group's own row for k < kGraphK (a group's 16 lanes cover 256 contiguous bytes per k); columns
+// beyond the row are -inf.  A group of 16 lanes is one DPP row, so the row maximum, the prefix sum of
+// the lanes' counts and the bit words below are DPP steps for all rows of the wave at once.
+constexpr int kGraphK = 5;                 // 5 x 64 columns: graphs of at most 320 nodes
+struct MaskRow {
+    float4 v[kGraphK];
+};
+
+__device__ __forceinline__ void load_mask_row(MaskRow &m, const float *bm, int N, int sub) {
+#pragma unroll
+    for (int k = 0; k < kGraphK; ++k) {
+        m.v[k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (64 * k < N) {                                // uniform
+            const int col = 64 * k + 4 * sub;
+            const float4 t = *reinterpret_cast<const float4 *>(bm + min(col, N - 4));      // N % 4 == 0: in bounds
+            if (col < N) m.v[k] = t;
+        }
+    }
+}
+
+// maximum / sum over the 16 lanes of a DPP row, in every lane of the row
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v, v));
+    v = fmaxf(v, dpp_f<0x4E>(v, v));
+    v = fmaxf(v, dpp_f<0x141>(v, v));
+    return fmaxf(v, dpp_f<0x140>(v, v));
+}
+__device__ __forceinline__ int row16_sum(int v) {
+    v += dpp_i<0xB1>(0, v);
+    v += dpp_i<0x4E>(0, v);
+    v += dpp_i<0x141>(0, v);
+    return v + dpp_i<0x140>(0, v);
+}
+// inclusive prefix sum inside each DPP row
+__device__ __forceinline__ int row16_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    return v + __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+}
+
+// Rows of 64 floats only (16 lanes per row = one DPP row): G is fixed, LPH selects the head layout.
+template <int LPH, bool SAVE>
+__global__ __launch_bounds__(kGraphFwdThreads) void dense_graph_fwd_kernel(MaskedFwdArgs a, int lc) {
+    constexpr int G = 16;
+    constexpr int RPW = 64 / G;
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char graph_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int sub = lane % G, grp = lane / G;
+    const int head = sub / LPH;
+    const int N = a.N;
+    const int NP = N + kGraphPadRows;
+    const int64_t b = blockIdx.x;
+    float *whs = reinterpret_cast<float *>(graph_smem);
+    float *f2s = whs + NP * HD;
+    uint16_t *lrow = reinterpret_cast<uint16_t *>(f2s + NP * H) + (wave * RPW + grp) * lc;     // this group's list; NP % 4 == 0: 16-byte aligned
+    const float *bmat = a.bias_mat + b * N * (int64_t)N;
+    MaskRow next;
+    int row0 = wave * RPW;
+    if (row0 < N) load_mask_row(next, bmat + min(row0 + grp, N - 1) * N, N, sub);          // in flight during the staging
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.Wh + b * N * (int64_t)HD);
+        for (int e = threadIdx.x; e < NP * (HD / 4); e += blockDim.x)
+            reinterpret_cast<float4 *>(whs)[e] = e < N * (HD / 4) ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float *src2 = a.f2 + b * N * (int64_t)H;
+        for (int e = threadIdx.x; e < NP * H; e += blockDim.x) f2s[e] = e < N * H ? src2[e] : -INFINITY;
+    }
+    __syncthreads();
+    const int W = (N + 31) / 32 + 1;
+    uint32_t *present_b = a.present ? a.present + b * N * (int64_t)W : nullptr;
+    const float *whl = whs + sub * 4;
+    const float *f2l = f2s + head;
+    for (; row0 < N; row0 += nwaves * RPW) {
+        const MaskRow cur = next;
+        if (row0 + nwaves * RPW < N)                     // the next rows travel during this quad's work
+            load_mask_row(next, bmat + min(row0 + nwaves * RPW + grp, N - 1) * N, N, sub);
+        const int i = min(row0 + grp, N - 1);
+        const bool row_ok = row0 + grp < N;
+        const float f1v = a.f1[(b * N + i) * H + head];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < kGraphK; ++k) mx = fmaxf(fmaxf(mx, fmaxf(cur.v[k].x, cur.v[k].y)), fmaxf(cur.v[k].z, cur.v[k].w));
+        mx = row16_max(mx);
+        const float cut = mx - kMaskCutoffFwd;
+        // bit 4k + c of `bits`: column 64k + 4 sub + c is visited.  A visited entry is non-zero iff the row's
+        // maximum is non-zero (it is visited itself) or the entry lies strictly between the cut and zero.
+        uint32_t bits = 0;
+        bool nonzero = mx != 0.f;
+#pragma unroll
+        for (int k = 0; k < kGraphK; ++k) {
+            const float comp[4] = {cur.v[k].x, cur.v[k].y, cur.v[k].z, cur.v[k].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool present = comp[c] > cut;
+                bits |= present ? (1u << (4 * k + c)) : 0u;
+                nonzero |= present && comp[c] < 0.f;
+            }
+        }
+        const int cnt = __popc(bits);
+        const int total = row16_sum(cnt);
+        int pos = row16_scan(cnt) - cnt;
+        const uint64_t nzb = __ballot(nonzero && bits != 0);
+        const bool anysoft = nzb != 0;
+        if (present_b && row_ok) {
+            uint32_t *prow = present_b + i * W;
+#pragma unroll
+            for (int k = 0; k < kGraphK; ++k) {
+                if (64 * k < N) {                         // words 2k and 2k + 1: columns of 8 adjacent lanes each
+                    const uint32_t w = or8_to_first(((bits >> (4 * k)) & 15u) << (4 * (sub & 7)));
+                    const int wi = 2 * k + (sub >> 3);
+                    if ((sub & 7) == 0 && wi < W - 1) prow[wi] = w;
+                }
+            }
+            if (sub == 0) prow[W - 1] = ((nzb >> (16 * grp)) & 0xffffull) != 0 ? 1u : 0u;
+        }
+        for (uint32_t rest = bits; __ballot(rest != 0) != 0;) {          // each lane appends its columns at its offset
+            if (rest != 0) {
+                const int t = __ffs(rest) - 1;
+                lrow[pos++] = (uint16_t)(64 * (t >> 2) + 4 * sub + (t & 3));
+                rest &= rest - 1;
+            }
+        }
+        if (sub < kGraphBatch) lrow[total + sub] = (uint16_t)N;          // padding: the dummy row
+        // the lists are written and read by this wave only; its lanes run in lockstep
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        MRowState st;
+        st.m = -INFINITY;
+        st.s = st.q = 0.f;
+        st.acc = st.pos = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row_ok) {
+            const float *bm_own = bmat + i * N;
+            if (anysoft) {                                // wave-uniform: biases are fetched for all of the wave's rows
+                for (int k = 0; k < total; k += kGraphBatch)
+                    graph_fwd_batch<G, LPH, SAVE, true>(st, a.slope, lrow + k, bm_own, N, whl, f2l, f1v);
+            } else {
+                for (int k = 0; k < total; k += kGraphBatch)
+                    graph_fwd_batch<G, LPH, SAVE, false>(st, a.slope, lrow + k, bm_own, N, whl, f2l, f1v);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                 // every lane is done with the lists before the next rows overwrite them
+        if (row_ok) {
+            const int64_t row = b * N + i;
+            const bool empty = !(st.s > 0.f);
+            const float inv = empty ? 0.f : 1.0f / st.s;
+            const float4 ag = f4_scale(inv, st.acc);
+            if (SAVE) {
+                *reinterpret_cast<float4 *>(a.agg + row * HD + sub * 4) = ag;
+                *reinterpret_cast<float4 *>(a.pos + row * HD + sub * 4) = f4_scale(inv, st.pos);
+                if (sub % LPH == 0) {
+                    a.lse[row * H + head] = empty ? 0.f : st.m + logf(st.s);
+                    a.q[row * H + head] = st.q * inv;
+                }
+            }
+            float4 r = ag;
+            if (a.bias) r = f4_add(r, *reinterpret_cast<const float4 *>(a.bias + sub * 4));
+            if (a.resid) r = f4_add(r, *reinterpret_cast<const float4 *>(a.resid + row * HD + sub * 4));
+            if (a.activation != GATMI_ACT_IDENTITY) r = make_float4(act_f(r.x, a.activation), act_f(r.y, a.activation), act_f(r.z, a.activation), act_f(r.w, a.activation));
+            *reinterpret_cast<float4 *>(a.out + row * HD + sub * 4) = r;
+        }
+    }
+}
+
+// head layouts of the graph-resident kernels (lanes per head; rows are always 64 floats: 16 lanes)
+#define GATMI_GRAPH_SHAPES(X) X(1) X(2) X(4) X(8) X(16)
+constexpr int kGraphMaxN = 64 * kGraphK;    // mask columns a lane group holds in registers
+constexpr int64_t kGraphMinBatch = 256;     // at least one block per CU, else the row-block kernels fill the chip better
+
 // ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
@@ -350,7 +595,7 @@ __device__ __forceinline__ void masked_bwd_batch(MSrcState &st, const MaskedBwdA
     int i[U];
     float4 gv[U];
     float f1v[U], lsev[U], cv[U], bv[U];
-    load_ids(lp, i);                                  // entries: row id | (needs its bias value) << 15
+    load_ids<U>(lp, i);                                  // entries: row id | (needs its bias value) << 15
 #pragma unroll
     for (int t = 0; t < U; ++t) {
         if (t >= nvalid) i[t] = i[0];
@@ -553,6 +798,27 @@ extern "C" int gatmi_dense_attn_fwd_masked(int64_t B, int32_t N, int32_t H, int3
     a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.activation = activation; a.slope = slope;
     a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.present = present;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // many small graphs: one block per graph with the graph's rows resident in LDS
+    const int lc = graph_list_capacity(N);
+    if (!drop && G == 16 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && graph_fwd_lds(N, G, H, lc) <= kGraphFwdLdsMax) {
+        const size_t lds = graph_fwd_lds(N, G, H, lc);
+        hipError_t e = hipSuccess;
+#define X(ll)                                                                                                      \
+        if (LPH == ll) {                                                                                          \
+            if (save) {                                                                                           \
+                if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_fwd_kernel<ll, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_fwd_kernel<ll, true>), dim3((unsigned)B), dim3(kGraphFwdThreads), lds, st, a, lc); \
+            } else {                                                                                              \
+                if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_fwd_kernel<ll, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_fwd_kernel<ll, false>), dim3((unsigned)B), dim3(kGraphFwdThreads), lds, st, a, lc); \
+            }                                                                                                     \
+            if (e != hipSuccess) return fail(GATMI_EHIP, "dense_attn_fwd_masked: %s", hipGetErrorString(e));       \
+            GATMI_LAUNCH_CHECK("dense_attn_fwd_masked (graph-resident)");                                         \
+            return GATMI_OK;                                                                                      \
+        }
+        GATMI_GRAPH_SHAPES(X)
+#undef X
+    }
     const int rows_per_block = 4 * (64 / G);
     const dim3 grid((unsigned)B, (unsigned)((N + rows_per_block - 1) / rows_per_block));
 #define X(gg, ll)                                                                                                 \

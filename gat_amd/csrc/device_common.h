@@ -23,6 +23,47 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// Cross-lane steps without LDS traffic (DPP modifiers; a __shfl is a ds_bpermute with LDS latency).
+// CTRL: 0xB1 / 0x4E swap lanes inside quads (xor 1 / xor 2), 0x141 / 0x140 mirror half rows / rows of
+// 16 lanes, 0x142 / 0x143 broadcast lane 15 / 31 of a row to the following rows, 0x100 + n takes the
+// lane n places up within its row of 16.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false); }
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+
+// maximum over the 64 lanes of a wave, returned in every lane
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v, v));
+    v = fmaxf(v, dpp_f<0x4E>(v, v));
+    v = fmaxf(v, dpp_f<0x141>(v, v));
+    v = fmaxf(v, dpp_f<0x140>(v, v));            // every lane of a row of 16 holds the row's maximum
+    v = fmaxf(v, dpp_f<0x142, 0xA>(v, v));       // rows 1 and 3 take in rows 0 and 2
+    v = fmaxf(v, dpp_f<0x143, 0xC>(v, v));       // rows 2 and 3 take in lane 31: lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// inclusive prefix sum over the 64 lanes of a wave (lane l gets v[0] + ... + v[l])
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);     // row_shr:1, lanes without a source add 0
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);     // scan inside each row of 16 lanes
+    v += dpp_i<0x142, 0xA>(0, v);                                      // rows 1 and 3 add the totals of rows 0 and 2
+    v += dpp_i<0x143, 0xC>(0, v);                                      // rows 2 and 3 add the total of rows 0 and 1
+    return v;
+}
+
+// OR over each aligned group of 8 lanes, valid in the group's first lane
+__device__ __forceinline__ uint32_t or8_to_first(uint32_t w) {
+    w |= (uint32_t)dpp_i<0xB1>(0, (int)w);
+    w |= (uint32_t)dpp_i<0x4E>(0, (int)w);
+    w |= (uint32_t)dpp_i<0x104>(0, (int)w);      // lane i takes lane i + 4 of its row
+    return w;
+}
+
 // Counter-based dropout mask: splitmix64 finaliser of (seed, index); keep when the top 24 bits,
 // read as a fraction in [0,1), fall below keep_prob.  The same function is restated on the host
 // by the tests to replay masks.

@@ -312,3 +312,37 @@ def test_row_masked_everywhere_stays_with_the_dense_kernels():
     # the oracle evaluated in fp32 (as TensorFlow does) swallows the logits of that row too
     assert_close(calls[0], ref_numpy.gat_layer_dense(x.cpu().numpy(), p, bm.astype(np.float32), ref_numpy.elu, "concat"),
                  rtol=1e-5, atol_scale=1e-5, what="fp32 oracle")
+
+
+@pytest.mark.parametrize("B,N,F,H,D,soft", [(256, 52, 6, 8, 8, False), (260, 264, 8, 8, 8, False), (256, 72, 5, 4, 8, True),
+                                             (300, 132, 7, 1, 64, False), (256, 8, 3, 2, 16, True)])
+def test_graph_resident_kernels_for_batches_of_many_small_graphs(B, N, F, H, D, soft):
+    """Batches of at least 256 graphs whose rows are a multiple of 16 bytes take the graph-resident form
+    of the list kernels (one block per graph, the graph's projected rows staged in LDS).  Graphs are
+    independent, so the float64 oracle checks the first and the last graphs of the batch, forward and
+    gradients of the inputs; the whole batch is compared with the matrix-core kernels."""
+    from gat_amd import ops
+    dev = torch.device("cuda:0")
+    bm = _masks(B, N, 0.1, 40 + N, soft=soft).astype(np.float32)
+    bm[5, N // 2, :] = -1e9                                   # a row masked everywhere: uniform attention in fp32 (checked against the matrix-core kernels)
+    p = layer_params(F, H, D, seed=N)
+    x = np.random.default_rng(N + 1).normal(0, 1, (B, N, F)).astype(np.float32)
+    dout = np.random.default_rng(N + 2).normal(0, 1, (B, N, H * D)).astype(np.float32)
+    res = {}
+    for path in ("lists", "dense"):
+        tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+        xt = torch.tensor(x, device=dev, requires_grad=True)
+        out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], torch.tensor(bm, device=dev),
+                                  ops.make_cfg(H, D, "elu", mask_path=path))
+        out.backward(torch.tensor(dout, device=dev))
+        res[path] = (out.detach().cpu().numpy(), xt.grad.cpu().numpy(), tp["W"].grad.cpu().numpy(), tp["a1"].grad.cpu().numpy(),
+                     tp["a2"].grad.cpu().numpy())
+    for a, b, name in zip(res["lists"], res["dense"], ("out", "dX", "dW", "da1", "da2")):
+        assert_close(a, b, rtol=1e-5, atol_scale=5e-6, what="graph-resident vs matrix cores " + name)
+    for sl in (slice(0, 3), slice(B - 2, B)):
+        rp = {k: torch.tensor(v, dtype=torch.float64) for k, v in p.items()}
+        rx = torch.tensor(x[sl].astype(np.float64), requires_grad=True)
+        ref = ref_torch.layer_dense(rx, rp, torch.tensor(bm[sl].astype(np.float64)), "elu", "concat")
+        ref.backward(torch.tensor(dout[sl].astype(np.float64)))
+        assert_close(res["lists"][0][sl], ref.detach().numpy(), what="graph-resident forward vs oracle")
+        assert_close(res["lists"][1][sl], rx.grad.numpy(), atol_scale=5e-6, what="graph-resident dX vs oracle")
