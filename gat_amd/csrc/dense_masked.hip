@@ -752,6 +752,157 @@ __global__ __launch_bounds__(256, GATMI_MASK_MINBLOCKS) void dense_masked_bwd_ke
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward, graph-resident form: one block per graph; the graph's g rows, per-node statistics and
+// visited-entry bits are staged in LDS once, and every wave takes source columns four at a time
+// (one per lane group): the 16 lanes of a group collect the destination rows whose bit for the
+// column is set (lane sub looks at rows sub, sub + 16, ...), a DPP prefix sum orders them into the
+// group's list, and the walk gathers from LDS.  Lists are padded with a dummy row (g = 0,
+// lse = +inf: coefficient exactly 0).  Same `present` format as dense_masked_bwd_kernel.
+// ------------------------------------------------------------------------------------------
+template <int LPH, bool SOFT>
+__device__ __forceinline__ void graph_bwd_batch(MSrcState &st, float slope, const uint16_t *lp, const float *bmcol, int N,
+                                                const float *gs, const float *ss, float f2v, float4 whj) {
+    constexpr int G = 16;
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    constexpr int U = kGraphBatch;
+    int i[U];
+    float4 gv[U];
+    float f1v[U], lsev[U], cv[U], bv[U];
+    load_ids<U>(lp, i);                                  // entries: row id | (needs its bias value) << 15
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        const bool soft = i[t] & 0x8000;
+        i[t] &= 0x7fff;
+        gv[t] = *reinterpret_cast<const float4 *>(gs + i[t] * HD);
+        const float *sp = ss + i[t] * (3 * H);
+        f1v[t] = sp[0];
+        lsev[t] = sp[H];
+        cv[t] = sp[2 * H];
+        bv[t] = 0.f;
+        if (SOFT) {
+            if (soft) bv[t] = bmcol[(uint32_t)min(i[t], N - 1) * (uint32_t)N];
+        }
+    }
+    float bdf2 = 0.f;
+    float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        const float z = f1v[t] + f2v;
+        const float alpha = exp_neg((SOFT ? leaky(z, slope) + bv[t] : leaky(z, slope)) - lsev[t]);
+        const float dalpha = group_sum<LPH>(dot4(gv[t], whj));
+        bdf2 += alpha * (dalpha - cv[t]) * (z > 0.f ? 1.f : slope);
+        bacc = f4_fma(alpha, gv[t], bacc);
+    }
+    st.acc = f4_add(st.acc, bacc);
+    st.df2 += bdf2;
+}
+
+constexpr int kGraphBwdRows = (kGraphMaxN + 15) / 16;    // destination rows a lane looks at per column
+
+// LDS of the graph-resident backward kernel: g [N + pad][64] | stats [N + pad][3H] | bits [N][W] | lists
+static inline size_t graph_bwd_lds(int N, int H, int lc) {
+    const int W = (N + 31) / 32 + 1;
+    return (size_t)(N + kGraphPadRows) * (64 + 3 * H) * sizeof(float) + (size_t)N * W * sizeof(uint32_t) +
+           (size_t)(kGraphFwdThreads / 64) * 4 * lc * sizeof(uint16_t);
+}
+
+template <int LPH>
+__global__ __launch_bounds__(kGraphFwdThreads) void dense_graph_bwd_kernel(MaskedBwdArgs a, int lc) {
+    constexpr int G = 16;
+    constexpr int RPW = 4;
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char graph_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int sub = lane % G, grp = lane / G;
+    const int head = sub / LPH;
+    const int N = a.N;
+    const int NP = N + kGraphPadRows;
+    const int W = (N + 31) / 32 + 1;
+    const int64_t b = blockIdx.x;
+    float *gs = reinterpret_cast<float *>(graph_smem);                        // [NP][HD]
+    float *ss = gs + NP * HD;                                                 // [NP][3H]
+    uint32_t *ps = reinterpret_cast<uint32_t *>(ss + NP * 3 * H);             // [N][W]
+    uint16_t *lrow = reinterpret_cast<uint16_t *>(ps + N * W) + (wave * RPW + grp) * lc;      // N * W even (N % 4 == 0): 8-byte aligned
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.g + b * N * (int64_t)HD);
+        for (int e = threadIdx.x; e < NP * (HD / 4); e += blockDim.x)
+            reinterpret_cast<float4 *>(gs)[e] = e < N * (HD / 4) ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float *src2 = a.stats + b * N * (int64_t)(3 * H);
+        for (int e = threadIdx.x; e < NP * 3 * H; e += blockDim.x) {
+            // dummy rows: f1 = 0, lse = +inf (coefficient 0), c = 0
+            const int k = (e % (3 * H)) / H;
+            ss[e] = e < N * 3 * H ? src2[e] : (k == 1 ? INFINITY : 0.f);
+        }
+        const uint32_t *src3 = a.present + b * N * (int64_t)W;
+        for (int e = threadIdx.x; e < N * W; e += blockDim.x) ps[e] = src3[e];
+    }
+    __syncthreads();
+    const float *gl = gs + sub * 4;
+    const float *sl = ss + head;
+    for (int j0 = wave * RPW; j0 < N; j0 += nwaves * RPW) {
+        const int jcol = min(j0 + grp, N - 1);
+        const bool col_ok = j0 + grp < N;
+        const int64_t j = b * N + jcol;
+        const float f2v = a.f2[j * H + head];
+        const float4 whj = *reinterpret_cast<const float4 *>(a.Wh + j * HD + sub * 4);
+        // bit r of `bits`: destination row 16 r + sub visited column jcol; `softs`: and needs its bias value
+        uint32_t bits = 0, softs = 0;
+        const int wj = jcol >> 5, bj = jcol & 31;
+#pragma unroll
+        for (int r = 0; r < kGraphBwdRows; ++r) {
+            const int i = 16 * r + sub;
+            if (16 * r < N) {                             // uniform
+                const int ic = min(i, N - 1);
+                const uint32_t word = ps[ic * W + wj], flag = ps[ic * W + W - 1];
+                const uint32_t bit = i < N ? (word >> bj) & 1u : 0u;
+                bits |= bit << r;
+                softs |= (bit & flag) << r;
+            }
+        }
+        const int cnt = __popc(bits);
+        const int total = row16_sum(cnt);
+        int pos = row16_scan(cnt) - cnt;
+        const bool anysoft = __ballot(softs != 0) != 0;
+        for (uint32_t rest = bits; __ballot(rest != 0) != 0;) {          // each lane appends its rows at its offset
+            if (rest != 0) {
+                const int t = __ffs(rest) - 1;
+                lrow[pos++] = (uint16_t)((16 * t + sub) | (((softs >> t) & 1u) << 15));
+                rest &= rest - 1;
+            }
+        }
+        if (sub < kGraphBatch) lrow[total + sub] = (uint16_t)N;          // padding: the dummy row
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        MSrcState st;
+        st.acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.df2 = 0.f;
+        if (col_ok) {
+            const float *bmcol = a.bias_mat + b * N * (int64_t)N + jcol;
+            if (anysoft) {
+                for (int k = 0; k < total; k += kGraphBatch) graph_bwd_batch<LPH, true>(st, a.slope, lrow + k, bmcol, N, gl, sl, f2v, whj);
+            } else {
+                for (int k = 0; k < total; k += kGraphBatch) graph_bwd_batch<LPH, false>(st, a.slope, lrow + k, bmcol, N, gl, sl, f2v, whj);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                 // every lane is done with the lists before the next columns overwrite them
+        if (col_ok) {
+            float4 r = st.acc;
+            if (a.a1) {
+                const float d1 = a.df1[j * H + head];
+                r = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + sub * 4), r);
+                r = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + sub * 4), r);
+            }
+            *reinterpret_cast<float4 *>(a.dWh + j * HD + sub * 4) = r;
+            if (sub % LPH == 0) a.df2[j * H + head] = st.df2;
+        }
+    }
+}
+
 // (G, LPH) pairs built: rows of 32..256 floats (narrower rows leave most of a wave idle in the
 // compaction; those shapes stay with the matrix-core kernels)
 #define GATMI_MASKED_SHAPES(X) X(8, 1) X(8, 2) X(8, 4) X(8, 8) X(16, 1) X(16, 2) X(16, 4) X(16, 8) X(16, 16) \
@@ -853,6 +1004,22 @@ extern "C" int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int3
     a.B = B; a.N = N; a.g = g; a.stats = stats; a.Wh = Wh; a.f2 = f2; a.bias_mat = bias_mat; a.df1 = df1; a.a1 = a1; a.a2 = a2;
     a.dWh = dWh; a.df2 = df2; a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.present = present;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // many small graphs: one block per graph with the graph's rows resident in LDS
+    const int lcg = graph_list_capacity(N);
+    if (!drop && G == 16 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && graph_bwd_lds(N, H, lcg) <= kGraphFwdLdsMax) {
+        const size_t glds = graph_bwd_lds(N, H, lcg);
+        hipError_t e = hipSuccess;
+#define X(ll)                                                                                                      \
+        if (LPH == ll) {                                                                                          \
+            if (glds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_bwd_kernel<ll>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds); \
+            if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_bwd_kernel<ll>), dim3((unsigned)B), dim3(kGraphFwdThreads), glds, st, a, lcg); \
+            if (e != hipSuccess) return fail(GATMI_EHIP, "dense_attn_bwd_masked: %s", hipGetErrorString(e));       \
+            GATMI_LAUNCH_CHECK("dense_attn_bwd_masked (graph-resident)");                                         \
+            return GATMI_OK;                                                                                      \
+        }
+        GATMI_GRAPH_SHAPES(X)
+#undef X
+    }
     const dim3 grid((unsigned)B, (unsigned)((N + kBwdCols - 1) / kBwdCols));
     const int n_chunks = std::min(kBwdChunks, (N + 63) / 64);
     const size_t lds = (size_t)kBwdCols * (n_chunks * 64 * sizeof(uint16_t) + (kBwdChunks + 1) * sizeof(int));
