@@ -134,6 +134,10 @@ __device__ __forceinline__ float act_f(float x, int activation) {
 __device__ __forceinline__ float act_grad_from_out(float y, int activation) {
     return activation == GATMI_ACT_ELU ? elu_grad_from_out(y) : (activation == GATMI_ACT_RELU ? (y > 0.f ? 1.f : 0.f) : 1.f);
 }
+// the same derivative in terms of the activation's INPUT x (ELU: exp(x) for x <= 0)
+__device__ __forceinline__ float act_grad_from_pre(float x, int activation) {
+    return activation == GATMI_ACT_ELU ? (x > 0.f ? 1.f : expf(x)) : (activation == GATMI_ACT_RELU ? (x > 0.f ? 1.f : 0.f) : 1.f);
+}
 __host__ __device__ inline bool act_known(int activation) {
     return activation == GATMI_ACT_IDENTITY || activation == GATMI_ACT_ELU || activation == GATMI_ACT_RELU;
 }

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void gat_fwd_merge_kernel(FwdArgs a, const int
 struct BwdNodeArgs {
     int64_t n;
     const float *dout, *out, *agg, *pos, *q, *f1, *lse;
+    const float *bias;         // with out == nullptr: the pre-activation is agg + bias, read from registers instead of `out`
     float *g, *stats, *df1, *ws;
     uint32_t *g16;             // optional bf16 copy of g (two values per dword), the table the per-source kernel gathers
     int activation, reduce;
@@ -264,13 +265,14 @@ __global__ __launch_bounds__(256) void gat_bwd_node_kernel(BwdNodeArgs a) {
     const int head = sub / LPH;
     const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
     float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 biasv = a.bias ? *reinterpret_cast<const float4 *>(a.bias + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp; row < a.n; row += stride) {
         float4 gv;
         if (a.reduce == GATMI_REDUCE_MEAN) {
             gv = f4_scale(1.0f / H, *reinterpret_cast<const float4 *>(a.dout + row * (4 * LPH) + (sub % LPH) * 4));
         } else {
             gv = *reinterpret_cast<const float4 *>(a.dout + row * HD + sub * 4);
-            if (a.activation != GATMI_ACT_IDENTITY) {
+            if (a.activation != GATMI_ACT_IDENTITY && a.out) {
                 const float4 o = *reinterpret_cast<const float4 *>(a.out + row * HD + sub * 4);
                 gv.x *= act_grad_from_out(o.x, a.activation);
                 gv.y *= act_grad_from_out(o.y, a.activation);
@@ -280,6 +282,14 @@ __global__ __launch_bounds__(256) void gat_bwd_node_kernel(BwdNodeArgs a) {
         }
         const float4 ag = *reinterpret_cast<const float4 *>(a.agg + row * HD + sub * 4);
         const float4 ps = *reinterpret_cast<const float4 *>(a.pos + row * HD + sub * 4);
+        if (a.reduce != GATMI_REDUCE_MEAN && a.activation != GATMI_ACT_IDENTITY && !a.out) {
+            // no residual: the layer's pre-activation is agg + bias, both at hand (saves the read of `out`)
+            const float4 pre = f4_add(ag, biasv);
+            gv.x *= act_grad_from_pre(pre.x, a.activation);
+            gv.y *= act_grad_from_pre(pre.y, a.activation);
+            gv.z *= act_grad_from_pre(pre.z, a.activation);
+            gv.w *= act_grad_from_pre(pre.w, a.activation);
+        }
         const float c = group_sum<LPH>(dot4(gv, ag));
         const float gp = group_sum<LPH>(dot4(gv, ps));
         if (a.g) *reinterpret_cast<float4 *>(a.g + row * HD + sub * 4) = gv;
@@ -699,7 +709,7 @@ extern "C" size_t gatmi_gat_bwd_node_ws_floats(int32_t H, int32_t dp) { return (
 
 extern "C" int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
                                   const float *dout, const float *out, const float *agg, const float *pos,
-                                  const float *q, const float *f1, const float *lse,
+                                  const float *q, const float *f1, const float *lse, const float *bias,
                                   int32_t activation, int32_t reduce, float slope,
                                   float *g, uint16_t *g16, float *stats, float *df1, float *dbias, float *ws, void *stream) {
     int G, LPH;
@@ -708,12 +718,13 @@ extern "C" int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
     GATMI_REQUIRE(n_dst >= 0, GATMI_EINVAL, "gat_bwd_node: negative size");
     GATMI_REQUIRE(dout && agg && pos && q && f1 && lse && (g || g16) && stats && df1 && ws, GATMI_EINVAL, "gat_bwd_node: null pointer");
     GATMI_REQUIRE_ALIGNED(g16);
-    GATMI_REQUIRE(activation == GATMI_ACT_IDENTITY || (act_known(activation) && out), GATMI_EUNSUPPORTED, "gat_bwd_node: activation %d (ELU and ReLU need `out`)", activation);
+    GATMI_REQUIRE(act_known(activation), GATMI_EUNSUPPORTED, "gat_bwd_node: activation %d", activation);
+    GATMI_REQUIRE_ALIGNED(bias);
     GATMI_REQUIRE(reduce == GATMI_REDUCE_CONCAT || (reduce == GATMI_REDUCE_MEAN && activation == GATMI_ACT_IDENTITY), GATMI_EUNSUPPORTED, "gat_bwd_node: reduce %d", reduce);
     GATMI_REQUIRE_ALIGNED(dout); GATMI_REQUIRE_ALIGNED(out); GATMI_REQUIRE_ALIGNED(agg); GATMI_REQUIRE_ALIGNED(pos);
     GATMI_REQUIRE_ALIGNED(g); GATMI_REQUIRE_ALIGNED(ws);
     BwdNodeArgs a;
-    a.n = n_dst; a.dout = dout; a.out = out; a.agg = agg; a.pos = pos; a.q = q; a.f1 = f1; a.lse = lse;
+    a.n = n_dst; a.dout = dout; a.out = out; a.bias = out ? nullptr : bias; a.agg = agg; a.pos = pos; a.q = q; a.f1 = f1; a.lse = lse;
     a.g = g; a.g16 = reinterpret_cast<uint32_t *>(g16); a.stats = stats; a.df1 = df1; a.ws = ws;
     a.activation = activation; a.reduce = reduce; a.slope = slope;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -417,14 +417,14 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             sweep(graph.items_csr, graph.split_csr, ws)
         if need_grad:
             ctx.pgraph, ctx.cfg, ctx.has_bias, ctx.replicate, ctx.overlap = pgraph, cfg, bias is not None, replicate, overlap
-            ctx.save_for_backward(x, Wp, a1p, a2p, feat, f1, f2, out, agg, pos, lse, q)
+            ctx.save_for_backward(x, Wp, a1p, a2p, feat, f1, f2, out, agg, pos, lse, q, biasp)
         if cfg.reduce == "mean":
             return out[:, :D] if D != dp else out
         return out.reshape(n, H, dp)[:, :, :D].reshape(n, H * D) if D != dp else out
 
     @staticmethod
     def backward(ctx, dout):
-        x, Wp, a1p, a2p, feat, f1, f2, out, agg, pos, lse, q = ctx.saved_tensors
+        x, Wp, a1p, a2p, feat, f1, f2, out, agg, pos, lse, q, biasp = ctx.saved_tensors
         pgraph, cfg = ctx.pgraph, ctx.cfg
         graph, ex = pgraph.graph, pgraph.exchange
         H, D, dp = cfg.H, cfg.D, cfg.dp
@@ -447,7 +447,7 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             df1 = ops._new((n, H), x)
         dbias = ops._new((hd,), x)
         ws = ops._new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x)
-        _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out), ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse),
+        _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), None, ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse), ptr(biasp),
                   ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, ptr(g), ptr(g16), ptr(stats), ptr(df1), ptr(dbias), ptr(ws), st)
         dfeat = ops._new((n_src, hd), x)
         df2 = ops._new((n_src, H), x)

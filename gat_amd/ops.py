@@ -162,14 +162,14 @@ class SparseGATLayerFn(torch.autograd.Function):
             ctx.graph, ctx.cfg = graph, cfg
             ctx.has_bias, ctx.has_res = bias is not None, W_res is not None
             ctx.sparse_x = x if sparse_x else None
-            ctx.save_for_backward(x.val if sparse_x else x, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q)
+            ctx.save_for_backward(x.val if sparse_x else x, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q, biasp)
         if cfg.reduce == "mean":
             return out[:, :D] if D != dp else out
         return out.reshape(n, H, dp)[:, :, :D].reshape(n, H * D) if D != dp else out
 
     @staticmethod
     def backward(ctx, dout):
-        x, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q = ctx.saved_tensors
+        x, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q, biasp = ctx.saved_tensors
         graph, cfg = ctx.graph, ctx.cfg
         H, D, dp = cfg.H, cfg.D, cfg.dp
         hd = H * dp
@@ -188,8 +188,10 @@ class SparseGATLayerFn(torch.autograd.Function):
         df1 = _new((n, H), x)
         dbias = _new((hd,), x)
         ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x)
-        _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out), ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse),
-                  _ACT[cfg.activation], _RED[cfg.reduce], cfg.slope, ptr(g), ptr(g16), ptr(stats), ptr(df1), ptr(dbias), ptr(ws), st)
+        # without a residual the pre-activation is agg + bias: the kernel then does not read `out`
+        _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out) if ctx.has_res else None, ptr(agg), ptr(pos), ptr(q), ptr(f1),
+                  ptr(lse), ptr(biasp), _ACT[cfg.activation], _RED[cfg.reduce], cfg.slope, ptr(g), ptr(g16), ptr(stats), ptr(df1),
+                  ptr(dbias), ptr(ws), st)
         gtab, gdt = (g16, _lib.DTYPE_BF16) if bf16 else (g, _lib.DTYPE_F32)
         dWh = _new((n, hd), x)
         df2 = _new((n, H), x)
@@ -310,13 +312,13 @@ class DenseGATLayerFn(torch.autograd.Function):
         if need_grad:
             ctx.cfg, ctx.dims, ctx.present = cfg, (B, N), present
             ctx.has_bias, ctx.has_res = bias is not None, W_res is not None
-            ctx.save_for_backward(x2, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q, bias_mat)
+            ctx.save_for_backward(x2, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q, bias_mat, biasp)
         o = out.reshape(B, N, H, dp)
         return (o[..., :D] if D != dp else o).reshape(B, N, H * D)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q, bias_mat = ctx.saved_tensors
+        x2, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q, bias_mat, biasp = ctx.saved_tensors
         cfg = ctx.cfg
         B, N = ctx.dims
         H, D, dp = cfg.H, cfg.D, cfg.dp
@@ -329,8 +331,9 @@ class DenseGATLayerFn(torch.autograd.Function):
         df1 = _new((n, H), x2)
         dbias = _new((hd,), x2)
         ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x2)
-        _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out), ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse),
-                  _ACT[cfg.activation], _lib.REDUCE_CONCAT, cfg.slope, ptr(g), None, ptr(stats), ptr(df1), ptr(dbias), ptr(ws), st)
+        _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out) if ctx.has_res else None, ptr(agg), ptr(pos), ptr(q), ptr(f1),
+                  ptr(lse), ptr(biasp), _ACT[cfg.activation], _lib.REDUCE_CONCAT, cfg.slope, ptr(g), None, ptr(stats), ptr(df1),
+                  ptr(dbias), ptr(ws), st)
         dWh = _new((n, hd), x2)
         df2 = _new((n, H), x2)
         if ctx.present is not None:
@@ -437,7 +440,7 @@ class BnfAggregateFn(torch.autograd.Function):
         stats = _new((n, 3 * H), xp)
         df1 = _new((n, H), xp)
         ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, fp),), xp)
-        _lib.call("gatmi_gat_bwd_node", n, H, fp, ptr(G), None, ptr(t2n), ptr(t2pos), ptr(q), ptr(f1), ptr(lse),
+        _lib.call("gatmi_gat_bwd_node", n, H, fp, ptr(G), None, ptr(t2n), ptr(t2pos), ptr(q), ptr(f1), ptr(lse), None,
                   _lib.ACT_IDENTITY, _lib.REDUCE_CONCAT, slope, ptr(g), None, ptr(stats), ptr(df1), None, ptr(ws), st)
         dx = _new((n, fp), xp)
         dA = _new((B, N, N), xp)

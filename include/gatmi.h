@@ -230,11 +230,14 @@ int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
  *   stats [n_dst, 3, H] = {f1, lse, c}, c = <g, agg> per head
  *   df1 [n_dst, H]   = (1 - slope) * (<g, pos> - c * q)     = sum_j dlogit_ij  (gradient of f_1)
  *   dbias [hd]       = sum_i g (NULL to skip);  dresid is g itself.
+ *   activation': ELU / ReLU need the layer's pre-activation.  Pass `out` (the saved output; required
+ *       when a residual was added) -- or out = NULL and the layer's `bias` [hd] (NULL = zeros): without
+ *       a residual the pre-activation is agg + bias, which saves reading `out` (a fifth of the traffic).
  *   ws: gatmi_gat_bwd_node_ws_floats(H, dp). */
 size_t gatmi_gat_bwd_node_ws_floats(int32_t H, int32_t dp);
 int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
                        const float *dout, const float *out, const float *agg, const float *pos,
-                       const float *q, const float *f1, const float *lse,
+                       const float *q, const float *f1, const float *lse, const float *bias,
                        int32_t activation, int32_t reduce, float slope,
                        float *g, uint16_t *g16, float *stats, float *df1, float *dbias, float *ws, void *stream);
 

@@ -104,8 +104,8 @@ def test_one_training_step_matches_the_oracle(cora):
     opt.zero_grad(set_to_none=True)
     (ce + pen).backward()
     assert_close(logits.detach().cpu().numpy(), cora["logits"], rtol=2e-5, atol_scale=4e-6, what="logits")
-    assert abs(float(ce) - cora["ce"]) <= 2e-6 * abs(cora["ce"]), (float(ce), cora["ce"])
-    assert abs(float(pen) - cora["l2"]) <= 2e-6 * abs(cora["l2"]), (float(pen), cora["l2"])
+    assert abs(float(ce.detach()) - cora["ce"]) <= 2e-6 * abs(cora["ce"]), (float(ce.detach()), cora["ce"])
+    assert abs(float(pen.detach()) - cora["l2"]) <= 2e-6 * abs(cora["l2"]), (float(pen.detach()), cora["l2"])
     assert abs(float(acc) - cora["acc"]) <= 1e-6, (float(acc), cora["acc"])
     gtol = []
     for li, m in enumerate(store.layers):
