@@ -78,12 +78,12 @@ def kernel_alg_bytes(name, E, N, H=HEADS, D=WIDTH, f_in=F_IN, s=4):
     s = bytes per element of the gathered table (4 fp32, 2 bf16)."""
     hd = H * D * 4
     hg = H * D * s
-    if name == "gatmi_gat_fwd":       # gather Wh row + f2 + col id per edge; f1, item, out per node
-        return E * (hg + H * 4 + 4) + N * (hd + H * 4 + 16)
+    if name == "gatmi_gat_fwd":       # gather Wh row + col id per edge (f2 is formed from the row); f1, item, out per node
+        return E * (hg + 4) + N * (hd + H * 4 + 16)
     if name == "gatmi_gat_bwd_csc":   # gather g row + {f1,lse,c} + row id per edge; Wh, f2, df1 in, dWh, df2 out per node
         return E * (hg + 3 * H * 4 + 4) + N * (2 * hd + 3 * H * 4 + 16)
-    if name == "gatmi_gat_bwd_node":  # dOut, out, agg, pos in; g out; small per-head vectors
-        return N * (5 * hd + 8 * H * 4)
+    if name == "gatmi_gat_bwd_node":  # dOut, agg, pos in (the activation's derivative comes from agg + bias); g out; small per-head vectors
+        return N * (4 * hd + 8 * H * 4)
     if name == "gatmi_proj_fwd":
         return N * (f_in * 4 + hd + 2 * H * 4)
     if name == "gatmi_proj_bwd_params":
@@ -120,7 +120,7 @@ class EventProfiler:
 # row, 2 per head; training, no dropout), as rocprofv3 prints it: a PMC traffic figure is only
 # attached to the line when it was counted on a kernel of exactly this name
 KERNEL_SYMBOL = {
-    "gatmi_gat_fwd": {"f32": "gat_fwd_kernel<16, 2, true, false, false>", "bf16": "gat_fwd_kernel<16, 2, true, false, true>"},
+    "gatmi_gat_fwd": {"f32": "gat_fwd_kernel<16, 2, true, false, false, true>", "bf16": "gat_fwd_kernel<16, 2, true, false, true, true>"},
     "gatmi_gat_bwd_csc": {"f32": "gat_bwd_csc_kernel<16, 2, false, false>", "bf16": "gat_bwd_csc_kernel<16, 2, false, true>"},
     "gatmi_gat_bwd_node": {"f32": "gat_bwd_node_kernel<16, 2>", "bf16": "gat_bwd_node_kernel<16, 2>"},
 }

@@ -46,15 +46,15 @@ _SIGNATURES = {
     "gatmi_proj_bwd_params_csr": (c_int, [P, P, P, c_int64, c_int32, P, P, P, P, c_int32, c_int32, P, P, P, P, P, P, P]),
     "gatmi_gat_fwd_ws_floats": (c_size_t, [c_int64, c_int32, c_int32]),
     "gatmi_to_bf16": (c_int, [P, c_int64, P, P]),
-    "gatmi_gat_fwd": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, P, c_int32, P, P, P, P, c_int32, c_int32,
+    "gatmi_gat_fwd": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, P, c_int32, P, P, P, P, P, P, c_int32, c_int32,
                               c_float, c_float, c_float, c_uint64, P, P, P, P, P, P, P]),
-    "gatmi_gat_fwd_noalloc": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, c_int64, P, P, c_int32, P, P, P, P,
+    "gatmi_gat_fwd_noalloc": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, c_int64, P, P, c_int32, P, P, P, P, P, P,
                                       c_int32, c_int32, c_float, c_float, c_float, c_uint64, P, P, P, P, P, P]),
     "gatmi_gat_bwd_node_ws_floats": (c_size_t, [c_int32, c_int32]),
     "gatmi_gat_bwd_node": (c_int, [c_int64, c_int32, c_int32, P, P, P, P, P, P, P, P, c_int32, c_int32, c_float,
                                    P, P, P, P, P, P, P]),
     "gatmi_gat_bwd_ws_floats": (c_size_t, [c_int64, c_int32, c_int32]),
-    "gatmi_gat_bwd_csc": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, P, P, c_int32, P, P, P, P, P, P,
+    "gatmi_gat_bwd_csc": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, P, P, c_int32, P, P, P, P, P, P, P, P,
                                   c_float, c_float, c_float, c_uint64, P, P, P, P]),
     "gatmi_gat_bwd_finalize": (c_int, [c_int64, c_int32, c_int32, P, P, P, P, P, P]),
     "gatmi_dense_attn_fwd": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, c_int32, c_float,

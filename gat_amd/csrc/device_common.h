@@ -15,14 +15,6 @@ __device__ __forceinline__ float exp_neg(float x) { return __builtin_amdgcn_exp2
 
 __device__ __forceinline__ float leaky(float z, float slope) { return fmaxf(z, z * slope); }
 
-// xor-butterfly sum over `N` adjacent lanes (N power of two <= 64).
-template <int N>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = 1; o < N; o <<= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 // Cross-lane steps without LDS traffic (DPP modifiers; a __shfl is a ds_bpermute with LDS latency).
 // CTRL: 0xB1 / 0x4E swap lanes inside quads (xor 1 / xor 2), 0x141 / 0x140 mirror half rows / rows of
 // 16 lanes, 0x142 / 0x143 broadcast lane 15 / 31 of a row to the following rows, 0x100 + n takes the
@@ -32,6 +24,22 @@ __device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_u
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_f(float old, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+
+// Sum over each aligned group of `N` adjacent lanes (N a power of two <= 64), returned in every lane
+// of the group and bit-identical in all of them: every step adds two numbers that are each the same
+// across the lanes that read them.  Up to 16 lanes the steps are DPP modifiers (quad swaps, then the
+// mirror of a half row / row: after the quad steps a quad holds one value, so the mirrored lane
+// carries the other quad's sum); wider groups go on with ds_bpermute.
+template <int N>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (N >= 2) v += dpp_f<0xB1>(v, v);
+    if constexpr (N >= 4) v += dpp_f<0x4E>(v, v);
+    if constexpr (N >= 8) v += dpp_f<0x141>(v, v);
+    if constexpr (N >= 16) v += dpp_f<0x140>(v, v);
+#pragma unroll
+    for (int o = 16; o < N; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
 // maximum over the 64 lanes of a wave, returned in every lane

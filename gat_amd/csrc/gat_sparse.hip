@@ -43,6 +43,7 @@ struct FwdArgs {
     const int32_t *col;
     const void *feat;          // gathered source rows, fp32 or bf16 (template parameter BF16)
     const float *f1, *f2, *bias, *resid;
+    const float *la2, *lb2;    // with f2 == nullptr: f2_j = <feat_j, la2> + lb2, formed from the gathered row (kernels built with F2ROW)
     float *out, *agg, *pos, *lse, *q, *ws;
     int64_t ws_slots;          // partial-result records `ws` has room for (pieces beyond it are dropped, never written)
     int activation, reduce;
@@ -55,10 +56,12 @@ struct RowState {
     float4 acc, pos;
 };
 
-// One batch of U neighbours of one row group.
-template <int G, int LPH, int U, bool SAVE, bool DROP, bool BF16>
+// One batch of U neighbours of one row group.  F2ROW: the source half of the logit is not gathered
+// from a table but formed from the gathered row itself, f2_j = <feat_j, a2> + b2 per head (utils/layers.py:15):
+// one request per entry less, for four multiply-adds and a cross-lane step in the shadow of the row load.
+template <int G, int LPH, int U, bool SAVE, bool DROP, bool BF16, bool F2ROW>
 __device__ __forceinline__ void fwd_batch(RowState &st, const FwdArgs &a, const int32_t *cp, int64_t epos,
-                                          float f1v, int sub, int head) {
+                                          float f1v, float4 a2v, float b2h, int sub, int head) {
     constexpr int H = G / LPH;
     constexpr int HD = 4 * G;
     int32_t j[U];
@@ -68,8 +71,12 @@ __device__ __forceinline__ void fwd_batch(RowState &st, const FwdArgs &a, const 
     for (int t = 0; t < U; ++t) j[t] = cp[t];
 #pragma unroll
     for (int t = 0; t < U; ++t) {
-        z[t] = f1v + a.f2[(int64_t)j[t] * H + head];
+        if (!F2ROW) z[t] = f1v + a.f2[(int64_t)j[t] * H + head];
         v[t] = load_row4<BF16>(a.feat, j[t], HD, sub * 4);
+    }
+    if (F2ROW) {
+#pragma unroll
+        for (int t = 0; t < U; ++t) z[t] = f1v + (group_sum<LPH>(dot4(v[t], a2v)) + b2h);
     }
     float e[U];
     float mn = st.m;
@@ -150,7 +157,7 @@ __device__ __forceinline__ void fwd_finish(const RowState &st, const FwdArgs &a,
     *reinterpret_cast<float4 *>(a.out + row * HD + sub * 4) = r;
 }
 
-template <int G, int LPH, bool SAVE, bool DROP, bool BF16>
+template <int G, int LPH, bool SAVE, bool DROP, bool BF16, bool F2ROW>
 __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
     constexpr int RPW = 64 / G;
     constexpr int H = G / LPH;
@@ -165,6 +172,12 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
     const int len = item.z;
     const int32_t *cp = a.col + item.y;
     const float f1v = a.f1[row * H + head];
+    float4 a2v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float b2h = 0.f;
+    if (F2ROW) {
+        a2v = *reinterpret_cast<const float4 *>(a.la2 + sub * 4);
+        if (a.lb2) b2h = a.lb2[head];
+    }
 
     RowState st;
     st.m = -INFINITY;
@@ -183,12 +196,12 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
         st.pos = *reinterpret_cast<const float4 *>(rec + 3 * H + HD + sub * 4);
     }
     int k = 0;
-    for (; k + 4 <= len; k += 4) fwd_batch<G, LPH, 4, SAVE, DROP, BF16>(st, a, cp + k, (int64_t)item.y + k, f1v, sub, head);
+    for (; k + 4 <= len; k += 4) fwd_batch<G, LPH, 4, SAVE, DROP, BF16, F2ROW>(st, a, cp + k, (int64_t)item.y + k, f1v, a2v, b2h, sub, head);
     if (k + 2 <= len) {
-        fwd_batch<G, LPH, 2, SAVE, DROP, BF16>(st, a, cp + k, (int64_t)item.y + k, f1v, sub, head);
+        fwd_batch<G, LPH, 2, SAVE, DROP, BF16, F2ROW>(st, a, cp + k, (int64_t)item.y + k, f1v, a2v, b2h, sub, head);
         k += 2;
     }
-    if (k < len) fwd_batch<G, LPH, 1, SAVE, DROP, BF16>(st, a, cp + k, (int64_t)item.y + k, f1v, sub, head);
+    if (k < len) fwd_batch<G, LPH, 1, SAVE, DROP, BF16, F2ROW>(st, a, cp + k, (int64_t)item.y + k, f1v, a2v, b2h, sub, head);
 
     if (item.w < 0) {
         fwd_finish<G, LPH, SAVE>(st, a, row, sub, head);
@@ -330,6 +343,7 @@ struct BwdCscArgs {
     const int32_t *rowidx, *perm;
     const void *g;             // gathered destination rows of g, fp32 or bf16 (template parameter BF16)
     const float *stats, *feat, *f2, *df1, *a1, *a2;
+    const float *la2, *lb2;    // with f2 == nullptr: f2_j = <feat_j, la2> + lb2, as the forward kernel formed it
     float *dfeat, *df2, *ws;
     float slope, coef_keep, feat_keep;
     uint64_t seed;
@@ -413,8 +427,20 @@ __global__ __launch_bounds__(256) void gat_bwd_csc_kernel(BwdCscArgs a) {
     const int64_t j = item.x;
     const int len = item.z;
     const int32_t *rp = a.rowidx + item.y;
-    const float f2v = a.f2[j * H + head];
     float4 whj = *reinterpret_cast<const float4 *>(a.feat + j * HD + sub * 4);
+    float f2v;
+    if (a.f2) {
+        f2v = a.f2[j * H + head];
+    } else {
+        // the same expression, on the same numbers, as gat_fwd_kernel<..., F2ROW>: a forward pass that
+        // gathered the bf16 table saw this row rounded to bf16
+        float4 w = whj;
+        if (BF16) {
+            const uint32_t lo = pack_bf16x2(w.x, w.y), hi = pack_bf16x2(w.z, w.w);
+            w = make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u));
+        }
+        f2v = group_sum<LPH>(dot4(w, *reinterpret_cast<const float4 *>(a.la2 + sub * 4))) + (a.lb2 ? a.lb2[head] : 0.f);
+    }
     if (DROP) {
         if (a.feat_keep < 1.f) whj = drop_feat(whj, a.seed, j, HD, sub * 4, a.feat_keep);
     }
@@ -494,16 +520,22 @@ static inline unsigned blocks_for(int64_t n_groups, int G) {
     X(16, 1) X(16, 2) X(16, 4) X(16, 8) X(16, 16) X(32, 2) X(32, 4) X(32, 8) X(32, 16) X(32, 32) \
     X(64, 2) X(64, 4) X(64, 8) X(64, 16) X(64, 32) X(64, 64)
 
+template <int G, int LPH, bool SAVE, bool DROP, bool BF16>
+static void launch_fwd_rows(const FwdArgs &a, unsigned nb, hipStream_t st) {
+    if (a.la2) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, SAVE, DROP, BF16, true>), dim3(nb), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, SAVE, DROP, BF16, false>), dim3(nb), dim3(256), 0, st, a);
+}
+
 template <int G, int LPH>
 static int launch_fwd(const FwdArgs &a, const int4 *split, int64_t n_split, bool save, bool drop, bool bf16, hipStream_t st) {
     const unsigned nb = blocks_for(a.n_items, G);
     if (nb) {
-        if (bf16 && save) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, true, false, true>), dim3(nb), dim3(256), 0, st, a);
-        else if (bf16) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, false, false, true>), dim3(nb), dim3(256), 0, st, a);
-        else if (save && drop) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, true, true, false>), dim3(nb), dim3(256), 0, st, a);
-        else if (save) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, true, false, false>), dim3(nb), dim3(256), 0, st, a);
-        else if (drop) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, false, true, false>), dim3(nb), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, false, false, false>), dim3(nb), dim3(256), 0, st, a);
+        if (bf16 && save) launch_fwd_rows<G, LPH, true, false, true>(a, nb, st);
+        else if (bf16) launch_fwd_rows<G, LPH, false, false, true>(a, nb, st);
+        else if (save && drop) launch_fwd_rows<G, LPH, true, true, false>(a, nb, st);
+        else if (save) launch_fwd_rows<G, LPH, true, false, false>(a, nb, st);
+        else if (drop) launch_fwd_rows<G, LPH, false, true, false>(a, nb, st);
+        else launch_fwd_rows<G, LPH, false, false, false>(a, nb, st);
         GATMI_LAUNCH_CHECK("gat_fwd");
     }
     if (n_split > 0) {
@@ -607,6 +639,7 @@ extern "C" size_t gatmi_gat_fwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp
 static int gat_fwd_impl(const char *name, int64_t n_dst, int32_t H, int32_t dp,
                         const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                         const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
+                        const float *logit_a2, const float *logit_b2,
                         const float *bias, const float *resid, int32_t activation, int32_t reduce,
                         float slope, float coef_keep, float feat_keep, uint64_t seed,
                         float *out, float *agg, float *pos, float *lse, float *q,
@@ -616,7 +649,10 @@ static int gat_fwd_impl(const char *name, int64_t n_dst, int32_t H, int32_t dp,
     if (rc) return rc;
     GATMI_REQUIRE(n_dst >= 0 && n_items >= 0 && n_split >= 0, GATMI_EINVAL, "%s: negative size", name);
     if (n_dst == 0 || n_items == 0) return GATMI_OK;
-    GATMI_REQUIRE(items && feat && f1 && f2 && out, GATMI_EINVAL, "%s: null pointer", name);
+    GATMI_REQUIRE(items && feat && f1 && out, GATMI_EINVAL, "%s: null pointer", name);
+    GATMI_REQUIRE((f2 != nullptr) != (logit_a2 != nullptr), GATMI_EINVAL, "%s: give either the table f2 or logit_a2 (f2 formed from the gathered rows), not both or neither", name);
+    GATMI_REQUIRE(logit_a2 || !logit_b2, GATMI_EINVAL, "%s: logit_b2 goes with logit_a2", name);
+    GATMI_REQUIRE_ALIGNED(logit_a2);
     GATMI_REQUIRE(n_split == 0 || (split && ws), GATMI_EINVAL, "%s: split rows need `split` and a partial-result store", name);
     GATMI_REQUIRE(act_known(activation), GATMI_EUNSUPPORTED, "%s: activation %d", name, activation);
     GATMI_REQUIRE(reduce == GATMI_REDUCE_CONCAT || (reduce == GATMI_REDUCE_MEAN && activation == GATMI_ACT_IDENTITY), GATMI_EUNSUPPORTED,
@@ -629,7 +665,7 @@ static int gat_fwd_impl(const char *name, int64_t n_dst, int32_t H, int32_t dp,
     FwdArgs a;
     a.items = reinterpret_cast<const int4 *>(items);
     a.n_items = n_items;
-    a.col = col; a.feat = feat; a.f1 = f1; a.f2 = f2; a.bias = bias; a.resid = resid;
+    a.col = col; a.feat = feat; a.f1 = f1; a.f2 = f2; a.la2 = logit_a2; a.lb2 = logit_b2; a.bias = bias; a.resid = resid;
     a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.ws = ws; a.ws_slots = ws_slots;
     a.activation = activation; a.reduce = reduce;
     a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
@@ -648,12 +684,13 @@ static int gat_fwd_impl(const char *name, int64_t n_dst, int32_t H, int32_t dp,
 extern "C" int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
                              const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                              const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
+                             const float *logit_a2, const float *logit_b2,
                              const float *bias, const float *resid, int32_t activation, int32_t reduce,
                              float slope, float coef_keep, float feat_keep, uint64_t seed,
                              float *out, float *agg, float *pos, float *lse, float *q,
                              float *ws, void *stream) {
     // the caller sized `ws` with gatmi_gat_fwd_ws_floats for its own slot count: no limit to enforce here
-    return gat_fwd_impl("gat_fwd", n_dst, H, dp, items, n_items, split, n_split, col, feat, feat_dtype, f1, f2, bias, resid,
+    return gat_fwd_impl("gat_fwd", n_dst, H, dp, items, n_items, split, n_split, col, feat, feat_dtype, f1, f2, logit_a2, logit_b2, bias, resid,
                         activation, reduce, slope, coef_keep, feat_keep, seed, out, agg, pos, lse, q, ws, INT64_MAX, stream);
 }
 
@@ -685,6 +722,7 @@ extern "C" int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
                                      const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                                      int64_t n_slots,
                                      const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
+                                     const float *logit_a2, const float *logit_b2,
                                      const float *bias, const float *resid, int32_t activation, int32_t reduce,
                                      float slope, float coef_keep, float feat_keep, uint64_t seed,
                                      float *out, float *agg, float *pos, float *lse, float *q, void *stream) {
@@ -701,7 +739,7 @@ extern "C" int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
     }
     // Nothing in the store has to start at zero: each piece's record is written whole by the row kernel
     // before the merge kernel, ordered behind it on `stream`, reads it.
-    return gat_fwd_impl("gat_fwd_noalloc", n_dst, H, dp, items, n_items, split, n_split, col, feat, feat_dtype, f1, f2, bias, resid,
+    return gat_fwd_impl("gat_fwd_noalloc", n_dst, H, dp, items, n_items, split, n_split, col, feat, feat_dtype, f1, f2, logit_a2, logit_b2, bias, resid,
                         activation, reduce, slope, coef_keep, feat_keep, seed, out, agg, pos, lse, q, ws, n_slots, stream);
 }
 
@@ -743,6 +781,7 @@ extern "C" int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
                                  const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                                  const int32_t *rowidx, const int32_t *perm,
                                  const void *g, int32_t g_dtype, const float *stats, const float *feat, const float *f2,
+                                 const float *logit_a2, const float *logit_b2,
                                  const float *df1, const float *a1, const float *a2,
                                  float slope, float coef_keep, float feat_keep, uint64_t seed,
                                  float *dfeat, float *df2, float *ws, void *stream) {
@@ -751,7 +790,10 @@ extern "C" int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
     if (rc) return rc;
     GATMI_REQUIRE(n_src >= 0 && n_items >= 0 && n_split >= 0, GATMI_EINVAL, "gat_bwd_csc: negative size");
     if (n_src == 0 || n_items == 0) return GATMI_OK;
-    GATMI_REQUIRE(items && g && stats && feat && f2 && dfeat && df2, GATMI_EINVAL, "gat_bwd_csc: null pointer");
+    GATMI_REQUIRE(items && g && stats && feat && dfeat && df2, GATMI_EINVAL, "gat_bwd_csc: null pointer");
+    GATMI_REQUIRE((f2 != nullptr) != (logit_a2 != nullptr), GATMI_EINVAL, "gat_bwd_csc: give either the table f2 or logit_a2 (f2 formed from the rows of feat), as the forward call did");
+    GATMI_REQUIRE(logit_a2 || !logit_b2, GATMI_EINVAL, "gat_bwd_csc: logit_b2 goes with logit_a2");
+    GATMI_REQUIRE_ALIGNED(logit_a2);
     GATMI_REQUIRE((a1 == nullptr) == (a2 == nullptr) && (!a1 || df1), GATMI_EINVAL, "gat_bwd_csc: a1, a2 and df1 go together");
     GATMI_REQUIRE(n_split == 0 || (split && ws), GATMI_EINVAL, "gat_bwd_csc: split rows need `split` and `ws`");
     GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "gat_bwd_csc: keep probabilities must be in (0,1]");
@@ -761,7 +803,7 @@ extern "C" int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
     BwdCscArgs a;
     a.items = reinterpret_cast<const int4 *>(items);
     a.n_items = n_items; a.rowidx = rowidx; a.perm = perm;
-    a.g = g; a.stats = stats; a.feat = feat; a.f2 = f2; a.df1 = df1; a.a1 = a1; a.a2 = a2;
+    a.g = g; a.stats = stats; a.feat = feat; a.f2 = f2; a.la2 = logit_a2; a.lb2 = logit_b2; a.df1 = df1; a.a1 = a1; a.a2 = a2;
     a.dfeat = dfeat; a.df2 = df2; a.ws = ws;
     a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
     const bool drop = coef_keep < 1.f || feat_keep < 1.f;

@@ -2,11 +2,11 @@
 torch.distributed; backend "nccl" is RCCL over xGMI).
 
 The reference has no multi-device code at all; what shards here is its per-destination structure:
-out_i needs only {Wh_j, f2_j : j in N(i)} (utils/layers.py:16-24).  Rank p owns a contiguous block
+out_i needs only {Wh_j : j in N(i)} (utils/layers.py:16-24; f2_j = <Wh_j, a2> + b2 follows from the row).  Rank p owns a contiguous block
 of destination rows, their X rows and their CSR rows.  Sources owned by other ranks ("halo") are
 listed once per (owner, requester) pair, sorted by global id, and appended after the owned rows:
 
-  forward   K1 on owned rows -> pack rows peers asked for -> all-to-all(v) of Wh and f2 rows on a
+  forward   K1 on owned rows -> pack rows peers asked for -> all-to-all(v) of the Wh rows on a
             communication stream WHILE the aggregation kernel sweeps the entries whose sources are
             owned -> second sweep over the entries that read halo rows, taking up each row's parked
             softmax state (two-phase work items, gatmi_work_items_phased)
@@ -371,10 +371,11 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         a2p = ops._pad_last(a2.reshape(H, D), D, dp).reshape(hd)
         n_proj = n_src if replicate else n          # rows this rank projects itself
         feat = ops._new((n_src, hd), x)
-        f2 = ops._new((n_src, H), x)
+        f2 = ops._new((n_src if cfg.storage == "bf16" else n_proj, H), x)
         f1 = ops._new((n_proj, H), x)
+        b2c = b2.reshape(H).contiguous()
         _lib.call("gatmi_proj_fwd", ptr(x), n_proj, F, x.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1.contiguous()),
-                  ptr(b2.contiguous()), H, dp, ptr(feat), ptr(f1), ptr(f2), None, None, None, st)
+                  ptr(b2c), H, dp, ptr(feat), ptr(f1), ptr(f2), None, None, None, st)
         bf16 = cfg.storage == "bf16"
         gtab, gdt = feat, _lib.DTYPE_F32
         if bf16:
@@ -384,7 +385,9 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             _lib.call("gatmi_to_bf16", ptr(feat), n_proj * hd, ptr(gtab), st)
         ticket = None
         if not replicate:
-            ticket = ex.gather_halo_pack([(gtab.view(torch.float32), hd // 2) if bf16 else (feat, hd), (f2, H)])
+            # fp32: only the Wh rows travel, the receiving sweep forms <Wh_j, a2> + b2 from them; bf16 rows
+            # would add their rounding to the logits, so there the fp32 f2 rows travel along
+            ticket = ex.gather_halo_pack([(gtab.view(torch.float32), hd // 2), (f2, H)] if bf16 else [(feat, hd)])
         biasp = None if bias is None else ops._pad_last(bias.reshape(H, D), D, dp).reshape(hd)
         need_grad = any(ctx.needs_input_grad)
         out = ops._new((n, dp if cfg.reduce == "mean" else hd), x)
@@ -393,9 +396,11 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             agg, pos = ops._new((n, hd), x), ops._new((n, hd), x)
             lse, q = ops._new((n, H), x), ops._new((n, H), x)
 
+        half = (ptr(f2), None, None) if bf16 else (None, ptr(a2p), ptr(b2c))        # the source half of the logits
+
         def sweep(items, split, ws):
             _lib.call("gatmi_gat_fwd", n, H, dp, ptr(items), len(items), ptr(split) if len(split) else None, len(split),
-                      ptr(graph.col), ptr(gtab), gdt, ptr(f1), ptr(f2), ptr(biasp), None,
+                      ptr(graph.col), ptr(gtab), gdt, ptr(f1), *half, ptr(biasp), None,
                       ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
                       ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
         two_phase = ticket is not None and overlap and len(pgraph.items_a) and len(pgraph.items_b)
@@ -417,14 +422,14 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             sweep(graph.items_csr, graph.split_csr, ws)
         if need_grad:
             ctx.pgraph, ctx.cfg, ctx.has_bias, ctx.replicate, ctx.overlap = pgraph, cfg, bias is not None, replicate, overlap
-            ctx.save_for_backward(x, Wp, a1p, a2p, feat, f1, f2, out, agg, pos, lse, q, biasp)
+            ctx.save_for_backward(x, Wp, a1p, a2p, feat, f1, f2, b2c, out, agg, pos, lse, q, biasp)
         if cfg.reduce == "mean":
             return out[:, :D] if D != dp else out
         return out.reshape(n, H, dp)[:, :, :D].reshape(n, H * D) if D != dp else out
 
     @staticmethod
     def backward(ctx, dout):
-        x, Wp, a1p, a2p, feat, f1, f2, out, agg, pos, lse, q, biasp = ctx.saved_tensors
+        x, Wp, a1p, a2p, feat, f1, f2, b2c, out, agg, pos, lse, q, biasp = ctx.saved_tensors
         pgraph, cfg = ctx.pgraph, ctx.cfg
         graph, ex = pgraph.graph, pgraph.exchange
         H, D, dp = cfg.H, cfg.D, cfg.dp
@@ -455,12 +460,14 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         if len(graph.split_csc):
             ws2 = ops._new((_lib.lib.gatmi_gat_bwd_ws_floats(graph.n_slots_csc, H, dp),), x)
 
+        half = (ptr(f2), None, None) if bf16 else (None, ptr(a2p), ptr(b2c))
+
         def sweep(items, split):
             if len(items) == 0:
                 return
             _lib.call("gatmi_gat_bwd_csc", n_src, H, dp, ptr(items), len(items), ptr(split) if len(split) else None, len(split),
                       ptr(graph.rowidx), ptr(graph.perm), ptr(g16 if bf16 else g), _lib.DTYPE_BF16 if bf16 else _lib.DTYPE_F32,
-                      ptr(stats), ptr(feat), ptr(f2), ptr(df1) if replicate else None, ptr(a1p) if replicate else None,
+                      ptr(stats), ptr(feat), *half, ptr(df1) if replicate else None, ptr(a1p) if replicate else None,
                       ptr(a2p) if replicate else None,
                       cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dfeat), ptr(df2), ptr(ws2), st)
         if replicate:

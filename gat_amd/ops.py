@@ -138,6 +138,11 @@ class SparseGATLayerFn(torch.autograd.Function):
         hd = H * dp
         st = _lib.current_stream()
         Wp, a1p, a2p, Wrp, Wh, f1, f2, res = _project(x, W, a1, a2, b1, b2, cfg, W_res, b_res)
+        # fp32 rows: the kernels form the source half of the logits, <Wh_j, a2> + b2, from the rows they gather
+        # (b2c given, no f2 table); bf16 rows would add their rounding to the logits, so that mode gathers the table
+        b2c = _f32(b2).reshape(H).contiguous() if cfg.storage != "bf16" else None
+        if b2c is not None:
+            f2 = None
         biasp = None if bias is None else _pad_last(bias.reshape(H, D), D, dp).reshape(hd)
         need_grad = any(ctx.needs_input_grad)
         out_w = dp if cfg.reduce == "mean" else hd
@@ -155,21 +160,21 @@ class SparseGATLayerFn(torch.autograd.Function):
             _lib.call("gatmi_to_bf16", ptr(Wh), n * hd, ptr(feat), st)
         _lib.call("gatmi_gat_fwd", n, H, dp, ptr(graph.items_csr), len(graph.items_csr),
                   ptr(graph.split_csr) if len(graph.split_csr) else None, len(graph.split_csr),
-                  ptr(graph.col), ptr(feat), fdt, ptr(f1), ptr(f2), ptr(biasp), ptr(res),
+                  ptr(graph.col), ptr(feat), fdt, ptr(f1), ptr(f2), ptr(a2p) if f2 is None else None, ptr(b2c), ptr(biasp), ptr(res),
                   _ACT[cfg.activation], _RED[cfg.reduce], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
                   ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
         if need_grad:
             ctx.graph, ctx.cfg = graph, cfg
             ctx.has_bias, ctx.has_res = bias is not None, W_res is not None
             ctx.sparse_x = x if sparse_x else None
-            ctx.save_for_backward(x.val if sparse_x else x, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q, biasp)
+            ctx.save_for_backward(x.val if sparse_x else x, Wp, a1p, a2p, Wrp, Wh, f1, f2, b2c, out, agg, pos, lse, q, biasp)
         if cfg.reduce == "mean":
             return out[:, :D] if D != dp else out
         return out.reshape(n, H, dp)[:, :, :D].reshape(n, H * D) if D != dp else out
 
     @staticmethod
     def backward(ctx, dout):
-        x, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q, biasp = ctx.saved_tensors
+        x, Wp, a1p, a2p, Wrp, Wh, f1, f2, b2c, out, agg, pos, lse, q, biasp = ctx.saved_tensors
         graph, cfg = ctx.graph, ctx.cfg
         H, D, dp = cfg.H, cfg.D, cfg.dp
         hd = H * dp
@@ -200,8 +205,8 @@ class SparseGATLayerFn(torch.autograd.Function):
             ws2 = _new((_lib.lib.gatmi_gat_bwd_ws_floats(graph.n_slots_csc, H, dp),), x)
         _lib.call("gatmi_gat_bwd_csc", n, H, dp, ptr(graph.items_csc), len(graph.items_csc),
                   ptr(graph.split_csc) if len(graph.split_csc) else None, len(graph.split_csc),
-                  ptr(graph.rowidx), ptr(graph.perm), ptr(gtab), gdt, ptr(stats), ptr(Wh), ptr(f2), ptr(df1), ptr(a1p), ptr(a2p),
-                  cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dWh), ptr(df2), ptr(ws2), st)
+                  ptr(graph.rowidx), ptr(graph.perm), ptr(gtab), gdt, ptr(stats), ptr(Wh), ptr(f2), ptr(a2p) if f2 is None else None, ptr(b2c),
+                  ptr(df1), ptr(a1p), ptr(a2p), cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dWh), ptr(df2), ptr(ws2), st)
         dx, dW, da1, da2, db1, db2, dWr = _project_backward(x, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
         db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None
         dbr = dbias.reshape(H, dp)[:, :D] if ctx.has_res else None

@@ -184,7 +184,13 @@ int gatmi_proj_bwd_params_csr(const int64_t *xt_rowptr, const int32_t *xt_row, c
  *       the rows named by the items are computed and written; the merge step runs for the rows in
  *       `split`; see gatmi_work_items_phased for the item encoding); col: CSR source ids
  *   feat [n_src, hd] gathered rows (Wh) stored as feat_dtype (GATMI_DTYPE_F32, or GATMI_DTYPE_BF16
- *       written by gatmi_to_bf16: dropout must then be off); f1 [n_dst, H]; f2 [n_src, H]
+ *       written by gatmi_to_bf16: dropout must then be off); f1 [n_dst, H]
+ *   the source half of the logits (layers.py:15), one of two forms:
+ *       f2 [n_src, H], a table the kernel gathers from (logit_a2 = logit_b2 = NULL), or
+ *       f2 = NULL and logit_a2 [hd] (+ logit_b2 [H], NULL = zeros): the kernel forms
+ *       f2_j = <feat_j, logit_a2> + logit_b2 per head from the row it gathers anyway, which saves one
+ *       request and 4H bytes per entry.  gatmi_gat_bwd_csc must be called in the same form, so that both
+ *       passes see bit-identical logits (with GATMI_DTYPE_BF16 rows f2 is formed from the rounded rows).
  *   bias [hd] or NULL; resid [n_dst, hd] or NULL (per head, added before the activation; with
  *       GATMI_REDUCE_MEAN it is averaged over the heads together with the aggregate and the bias)
  *   out [n_dst, hd] (concat) or [n_dst, dp] (mean)
@@ -198,6 +204,7 @@ size_t gatmi_gat_fwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp);
 int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
                   const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                   const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
+                  const float *logit_a2, const float *logit_b2,
                   const float *bias, const float *resid, int32_t activation, int32_t reduce,
                   float slope, float coef_keep, float feat_keep, uint64_t seed,
                   float *out, float *agg, float *pos, float *lse, float *q,
@@ -220,6 +227,7 @@ int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
                           const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                           int64_t n_slots,
                           const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
+                          const float *logit_a2, const float *logit_b2,
                           const float *bias, const float *resid, int32_t activation, int32_t reduce,
                           float slope, float coef_keep, float feat_keep, uint64_t seed,
                           float *out, float *agg, float *pos, float *lse, float *q, void *stream);
@@ -244,14 +252,19 @@ int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
 /* Backward, per-source part: transposed SpMM + SDDMM over the CSC structure.
  *   items/split: gatmi_work_items of colptr; rowidx: CSC destination ids; perm: CSR position of
  *   each CSC entry (only read when coef_keep < 1, may be NULL otherwise)
+ *   g [n_dst, hd] (fp32 or bf16) and stats [n_dst, 3, H] from gatmi_gat_bwd_node
  *   dfeat [n_src, hd] = sum_i alpha_ij g_i  (+ df1_j a1 + df2_j a2 when a1 != NULL: then dfeat
  *       is the full gradient of Wh = seq_fts and df1 [n_src, H] must be given)
- *   df2 [n_src, H]    = sum_i dlogit_ij */
+ *   df2 [n_src, H]    = sum_i dlogit_ij
+ *   f2 / logit_a2 / logit_b2: the source half of the logits in the form the forward call used (table, or
+ *       formed from the rows of feat; with g_dtype GATMI_DTYPE_BF16 from those rows rounded to bf16, which
+ *       is what a forward pass over the bf16 table saw). */
 size_t gatmi_gat_bwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp);
 int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
                       const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                       const int32_t *rowidx, const int32_t *perm,
                       const void *g, int32_t g_dtype, const float *stats, const float *feat, const float *f2,
+                      const float *logit_a2, const float *logit_b2,
                       const float *df1, const float *a1, const float *a2,
                       float slope, float coef_keep, float feat_keep, uint64_t seed,
                       float *dfeat, float *df2, float *ws, void *stream);

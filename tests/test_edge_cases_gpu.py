@@ -72,7 +72,7 @@ def test_graph_without_edges_and_zero_sizes():
     # zero rows through the C ABI: accepted, nothing launched
     st = _lib.current_stream()
     _lib.call("gatmi_proj_fwd", None, 0, 5, 5, None, None, None, None, None, 2, 4, None, None, None, None, None, None, st)
-    _lib.call("gatmi_gat_fwd", 0, 2, 4, None, 0, None, 0, None, None, 0, None, None, None, None, 1, 0,
+    _lib.call("gatmi_gat_fwd", 0, 2, 4, None, 0, None, 0, None, None, 0, None, None, None, None, None, None, 1, 0,
               0.2, 1.0, 1.0, 0, None, None, None, None, None, None, st)
     _lib.call("gatmi_dense_attn_fwd", 0, 16, 8, 8, None, None, None, None, None, None, 1, 0.2, 1.0, 1.0, 0,
               None, None, None, None, None, st)
@@ -117,7 +117,7 @@ def test_c_abi_rejects_what_it_is_not_built_for():
     st = _lib.current_stream()
     t = torch.zeros(64, device="cuda:0")
     cases = [
-        ("gatmi_gat_fwd", (4, 3, 8, None, 0, None, 0, None, None, 0, None, None, None, None, 1, 0, 0.2, 1.0, 1.0, 0,
+        ("gatmi_gat_fwd", (4, 3, 8, None, 0, None, 0, None, None, 0, None, None, None, None, None, None, 1, 0, 0.2, 1.0, 1.0, 0,
                            None, None, None, None, None, None, st), "power of two"),                       # 3 heads
         ("gatmi_ipd_fwd", (1, 4, 129, t.data_ptr(), 2, 1.0, 0, t.data_ptr(), st), "128"),                  # too wide
         ("gatmi_ipd_fwd", (1, 4, 8, t.data_ptr(), 7, 1.0, 0, t.data_ptr(), st), "activation"),

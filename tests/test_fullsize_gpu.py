@@ -60,7 +60,7 @@ def test_gradient_checksums_and_determinism(big):
         out, agg, pos, lse, q = new(n, hd), new(n, hd), new(n, hd), new(n, H), new(n, H)
         ws = new(_lib.lib.gatmi_gat_fwd_ws_floats(g.n_slots_csr, H, D))
         _lib.call("gatmi_gat_fwd", n, H, D, ptr(g.items_csr), len(g.items_csr), ptr(g.split_csr), len(g.split_csr),
-                  ptr(g.col), ptr(Wh), _lib.DTYPE_F32, ptr(f1), ptr(f2), ptr(p["bias"].reshape(-1).contiguous()), None,
+                  ptr(g.col), ptr(Wh), _lib.DTYPE_F32, ptr(f1), ptr(f2), None, None, ptr(p["bias"].reshape(-1).contiguous()), None,
                   _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, 1.0, 1.0, 0, ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
         gg, stats, df1, dbias = new(n, hd), new(n, 3 * H), new(n, H), new(hd)
         wsn = new(_lib.lib.gatmi_gat_bwd_node_ws_floats(H, D))
@@ -77,7 +77,7 @@ def test_gradient_checksums_and_determinism(big):
         dfeat, df2 = new(n, hd), new(n, H)
         wsb = new(_lib.lib.gatmi_gat_bwd_ws_floats(g.n_slots_csc, H, D))
         _lib.call("gatmi_gat_bwd_csc", n, H, D, ptr(g.items_csc), len(g.items_csc), ptr(g.split_csc), len(g.split_csc),
-                  ptr(g.rowidx), None, ptr(gg), _lib.DTYPE_F32, ptr(stats), ptr(Wh), ptr(f2), None, None, None,
+                  ptr(g.rowidx), None, ptr(gg), _lib.DTYPE_F32, ptr(stats), ptr(Wh), ptr(f2), None, None, None, None, None,
                   0.2, 1.0, 1.0, 0, ptr(dfeat), ptr(df2), ptr(wsb), st)
         outs.append((out, dfeat, df2, df1, dbias, gg))
     (out, dfeat, df2, df1, dbias, gg), second = outs

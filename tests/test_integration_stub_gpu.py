@@ -64,7 +64,9 @@ def test_ctypes_only_sp_attn_head():
                         ptr(wh), ptr(f1), ptr(f2), None, None, None, stream), "proj_fwd")
     ws = alloc(g.gatmi_gat_fwd_ws_floats(i64(nl.value), H, dp))
     ok(g.gatmi_gat_fwd(i64(n), H, dp, upload(items), i64(ni.value), upload(split[:ns.value]), i64(ns.value), upload(col[:nnz.value]),
-                       ptr(wh), 0, ptr(f1), ptr(f2), dp_["bias"], None,
+                       ptr(wh), 0, ptr(f1),
+                       None, dp_["a2"], dp_["b2"],   # f2 formed from the gathered rows (or: f2, None, None to gather the table)
+                       dp_["bias"], None,
                        1,      # GATMI_ACT_ELU
                        0,      # GATMI_REDUCE_CONCAT
                        ctypes.c_float(0.2), ctypes.c_float(1.0), ctypes.c_float(1.0), ctypes.c_uint64(0),

@@ -185,3 +185,61 @@ def test_bf16_gather_tables_stay_within_the_bf16_class(H, D, activation, reduce)
     assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), rtol=2e-2, atol_scale=2e-2, what="bf16 dX")
     for k in ("W", "a1", "a2", "bias"):
         assert_close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), rtol=2e-2, atol_scale=2e-2, what="bf16 d" + k)
+
+
+@pytest.mark.parametrize("H,D", [(8, 8), (4, 4), (2, 16), (1, 64)])
+def test_source_logit_half_formed_from_the_rows_matches_the_table(H, D):
+    """gatmi_gat_fwd / gatmi_gat_bwd_csc take the source half of the logits (utils/layers.py:15) either as
+    the table f2 the projection wrote, or as (a2, b2) and form <Wh_j, a2> + b2 from the rows they gather.
+    Both forms are the same fp32 sum in a different order: results agree to rounding, and the row form
+    is the one the layers use (so it is also what every oracle comparison above exercises)."""
+    from gat_amd import CSRGraph, _lib, ops
+    from gat_amd._lib import ptr
+    dev = torch.device("cuda:0")
+    n, F = 700, 20
+    dst, src = random_graph(n, 6.0, seed=21, hubs=2, hub_deg=500)
+    graph = CSRGraph.from_coo(dst, src, n, dev, chunk=128)
+    p = layer_params(F, H, D, seed=22)
+    tp = {k: torch.tensor(v, dtype=torch.float32, device=dev) for k, v in p.items()}
+    x = torch.tensor(np.random.default_rng(23).normal(0, 1, (n, F)), dtype=torch.float32, device=dev)
+    cfg = ops.make_cfg(H, D, "elu", "concat")
+    dp, hd = cfg.dp, H * cfg.dp
+    _, a1p, a2p, _, Wh, f1, f2, _ = ops._project(x, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], cfg)
+    b2c = tp["b2"].reshape(H).contiguous()
+    st = _lib.current_stream()
+    new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    dout = torch.tensor(np.random.default_rng(24).normal(0, 1, (n, hd)), dtype=torch.float32, device=dev)
+
+    def run(form):
+        half = (ptr(f2), None, None) if form == "table" else (None, ptr(a2p), ptr(b2c))
+        out, agg, pos, lse, q = new(n, hd), new(n, hd), new(n, hd), new(n, H), new(n, H)
+        ws = new(max(1, _lib.lib.gatmi_gat_fwd_ws_floats(graph.n_slots_csr, H, dp)))
+        _lib.call("gatmi_gat_fwd", n, H, dp, ptr(graph.items_csr), len(graph.items_csr), ptr(graph.split_csr), len(graph.split_csr),
+                  ptr(graph.col), ptr(Wh), _lib.DTYPE_F32, ptr(f1), *half, None, None, _lib.ACT_ELU, _lib.REDUCE_CONCAT,
+                  0.2, 1.0, 1.0, 0, ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
+        g, stats, df1, dbias = new(n, hd), new(n, 3 * H), new(n, H), new(hd)
+        wsn = new(_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp))
+        _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), None, ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse), None,
+                  _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(g), None, ptr(stats), ptr(df1), ptr(dbias), ptr(wsn), st)
+        dfeat, df2 = new(n, hd), new(n, H)
+        wsb = new(max(1, _lib.lib.gatmi_gat_bwd_ws_floats(graph.n_slots_csc, H, dp)))
+        _lib.call("gatmi_gat_bwd_csc", n, H, dp, ptr(graph.items_csc), len(graph.items_csc), ptr(graph.split_csc), len(graph.split_csc),
+                  ptr(graph.rowidx), None, ptr(g), _lib.DTYPE_F32, ptr(stats), ptr(Wh), *half, ptr(df1), ptr(a1p), ptr(a2p),
+                  0.2, 1.0, 1.0, 0, ptr(dfeat), ptr(df2), ptr(wsb), st)
+        torch.cuda.synchronize()
+        return {"out": out, "lse": lse, "q": q, "dfeat": dfeat, "df2": df2, "df1": df1}
+
+    assert len(graph.split_csr) and len(graph.split_csc)
+    table, rows = run("table"), run("rows")
+    for k in table:
+        assert_close(rows[k].cpu().numpy(), table[k].cpu().numpy().astype(np.float64), rtol=2e-5, atol_scale=2e-6, what="row form " + k)
+    # the coefficient rows the backward pass rebuilds from the row form sum to one like the forward pass's:
+    # column sums of sum_i alpha_ij g_i equal those of g only if both passes saw the same logits
+    again = run("rows")
+    for k in rows:
+        assert torch.equal(rows[k], again[k])
+    # giving both forms, or neither, is refused
+    rc = _lib.lib.gatmi_gat_fwd(n, H, dp, ptr(graph.items_csr), len(graph.items_csr), None, 0, ptr(graph.col), ptr(Wh), _lib.DTYPE_F32,
+                                ptr(f1), ptr(f2), ptr(a2p), None, None, None, _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, 1.0, 1.0, 0,
+                                ptr(new(n, hd)), None, None, None, None, None, st)
+    assert rc == -1 and "either" in _lib.last_error()          # GATMI_EINVAL
