@@ -128,6 +128,19 @@ __device__ __forceinline__ float4 f4_add(float4 x, float4 y) {
     const f32x2_t lo = (f32x2_t){x.x, x.y} + (f32x2_t){y.x, y.y}, hi = (f32x2_t){x.z, x.w} + (f32x2_t){y.z, y.w};
     return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
+// Store of a result row that this kernel does not read again: the non-temporal hint keeps the written
+// lines from displacing the gathered table in L2.
+__device__ __forceinline__ void store_stream4(float *p, float4 v) {
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store((f32x4_t){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_t *>(p));
+}
+// Load of a row that a streaming kernel reads exactly once.  (Index streams are better left alone: with
+// the hint the four ids of a batch are no longer fetched as one 16-byte load.)
+__device__ __forceinline__ float4 load_stream4(const float *p) {
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float dot4(float4 x, float4 y) { return fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, x.w * y.w))); }
 
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }

@@ -126,8 +126,8 @@ __device__ __forceinline__ void fwd_finish(const RowState &st, const FwdArgs &a,
     const float inv = empty ? 0.f : 1.0f / st.s;
     const float4 ag = f4_scale(inv, st.acc);
     if (SAVE) {
-        *reinterpret_cast<float4 *>(a.agg + row * HD + sub * 4) = ag;
-        *reinterpret_cast<float4 *>(a.pos + row * HD + sub * 4) = f4_scale(inv, st.pos);
+        store_stream4(a.agg + row * HD + sub * 4, ag);
+        store_stream4(a.pos + row * HD + sub * 4, f4_scale(inv, st.pos));
         if (sub % LPH == 0) {
             a.lse[row * H + head] = empty ? 0.f : st.m + logf(st.s);
             a.q[row * H + head] = st.q * inv;
@@ -154,7 +154,7 @@ __device__ __forceinline__ void fwd_finish(const RowState &st, const FwdArgs &a,
     }
     if (a.resid) r = f4_add(r, *reinterpret_cast<const float4 *>(a.resid + row * HD + sub * 4));
     if (a.activation != GATMI_ACT_IDENTITY) r = make_float4(act_f(r.x, a.activation), act_f(r.y, a.activation), act_f(r.z, a.activation), act_f(r.w, a.activation));
-    *reinterpret_cast<float4 *>(a.out + row * HD + sub * 4) = r;
+    store_stream4(a.out + row * HD + sub * 4, r);
 }
 
 template <int G, int LPH, bool SAVE, bool DROP, bool BF16, bool F2ROW>
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void gat_bwd_node_kernel(BwdNodeArgs a) {
         if (a.reduce == GATMI_REDUCE_MEAN) {
             gv = f4_scale(1.0f / H, *reinterpret_cast<const float4 *>(a.dout + row * (4 * LPH) + (sub % LPH) * 4));
         } else {
-            gv = *reinterpret_cast<const float4 *>(a.dout + row * HD + sub * 4);
+            gv = load_stream4(a.dout + row * HD + sub * 4);
             if (a.activation != GATMI_ACT_IDENTITY && a.out) {
                 const float4 o = *reinterpret_cast<const float4 *>(a.out + row * HD + sub * 4);
                 gv.x *= act_grad_from_out(o.x, a.activation);
@@ -293,8 +293,8 @@ __global__ __launch_bounds__(256) void gat_bwd_node_kernel(BwdNodeArgs a) {
                 gv.w *= act_grad_from_out(o.w, a.activation);
             }
         }
-        const float4 ag = *reinterpret_cast<const float4 *>(a.agg + row * HD + sub * 4);
-        const float4 ps = *reinterpret_cast<const float4 *>(a.pos + row * HD + sub * 4);
+        const float4 ag = load_stream4(a.agg + row * HD + sub * 4);
+        const float4 ps = load_stream4(a.pos + row * HD + sub * 4);
         if (a.reduce != GATMI_REDUCE_MEAN && a.activation != GATMI_ACT_IDENTITY && !a.out) {
             // no residual: the layer's pre-activation is agg + bias, both at hand (saves the read of `out`)
             const float4 pre = f4_add(ag, biasv);
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void gat_bwd_node_kernel(BwdNodeArgs a) {
         }
         const float c = group_sum<LPH>(dot4(gv, ag));
         const float gp = group_sum<LPH>(dot4(gv, ps));
-        if (a.g) *reinterpret_cast<float4 *>(a.g + row * HD + sub * 4) = gv;
+        if (a.g) store_stream4(a.g + row * HD + sub * 4, gv);
         if (a.g16) *reinterpret_cast<uint2 *>(a.g16 + (row * HD + sub * 4) / 2) = make_uint2(pack_bf16x2(gv.x, gv.y), pack_bf16x2(gv.z, gv.w));
         if (sub % LPH == 0) {
             const float qv = a.q[row * H + head];
@@ -409,7 +409,7 @@ __device__ __forceinline__ void bwd_finish(const SrcState &st, const BwdCscArgs 
         r = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + sub * 4), r);
         r = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + sub * 4), r);
     }
-    *reinterpret_cast<float4 *>(a.dfeat + j * HD + sub * 4) = r;
+    store_stream4(a.dfeat + j * HD + sub * 4, r);
     if (sub % LPH == 0) a.df2[j * H + head] = st.df2;
 }
 

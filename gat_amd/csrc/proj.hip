@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64 * kResWaves) void proj_resident_kernel(GemmArgs 
             }
             if (row < g.n && col < g.Nc) {
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                *reinterpret_cast<float4 *>(g.C + row * g.ldc + col) = v;
+                store_stream4(g.C + row * g.ldc + col, v);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -536,8 +536,8 @@ __global__ __launch_bounds__(256, 3) void xt_gemm_lines_kernel(const float *X, i
             f32x4 xa[FS];
 #pragma unroll
             for (int fs = 0; fs < FS; ++fs)
-                xa[fs] = (nok && fok[fs]) ? *reinterpret_cast<const f32x4 *>(X + node * ldx + f0 + 64 * fs + 4 * m) : zero;
-            const f32x4 yb = (nok && yok) ? *reinterpret_cast<const f32x4 *>(dY + node * hd + y0 + 4 * m) : zero;
+                xa[fs] = (nok && fok[fs]) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(X + node * ldx + f0 + 64 * fs + 4 * m)) : zero;
+            const f32x4 yb = (nok && yok) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(dY + node * hd + y0 + 4 * m)) : zero;
 #pragma unroll
             for (int fs = 0; fs < FS; ++fs)
 #pragma unroll
@@ -596,13 +596,26 @@ __global__ __launch_bounds__(256) void attn_param_grad_kernel(const float *Wh, c
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     float t1 = 0.f, t2 = 0.f;
     const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
-    for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp; row < n; row += stride) {
-        const float4 v = *reinterpret_cast<const float4 *>(Wh + row * HD + sub * 4);
-        const float d1 = df1[row * H + head], d2 = df2[row * H + head];
-        s1.x += d1 * v.x; s1.y += d1 * v.y; s1.z += d1 * v.z; s1.w += d1 * v.w;
-        s2.x += d2 * v.x; s2.y += d2 * v.y; s2.z += d2 * v.z; s2.w += d2 * v.w;
-        t1 += d1;
-        t2 += d2;
+    // four rows per lane group in flight (the loop is a plain stream: its speed is the bytes it keeps outstanding);
+    // rows beyond n contribute exact zeros, the order of the sums does not depend on the grid
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp; row0 < n; row0 += 4 * stride) {
+        float4 v[4];
+        float d1[4], d2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t row = row0 + u * stride;
+            const bool ok = row < n;
+            v[u] = ok ? load_stream4(Wh + row * HD + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            d1[u] = ok ? df1[row * H + head] : 0.f;
+            d2[u] = ok ? df2[row * H + head] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s1 = f4_fma(d1[u], v[u], s1);
+            s2 = f4_fma(d2[u], v[u], s2);
+            t1 += d1[u];
+            t2 += d2[u];
+        }
     }
     // block partial layout in ws: [da1 HD | da2 HD | db1 H | db2 H]
     float *out = ws + (int64_t)blockIdx.x * (2 * HD + 2 * H);

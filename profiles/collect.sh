@@ -17,6 +17,7 @@ pmc() {   # pmc <name> <counters...> -- <program args...>
     while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
     shift
     echo "[collect] pmc $name: ${ctrs[*]}"
+    rm -rf "$OUT/pmc_$name"
     timeout -s KILL 240 rocprofv3 --pmc "${ctrs[@]}" -d "$OUT/pmc_$name" --output-format csv -- python3 "$@" > "$OUT/pmc_$name.log" 2>&1 || { echo "[collect] pmc $name failed"; return 1; }
 }
 
@@ -27,6 +28,7 @@ for part in $PARTS; do
         timeout -k 10 400 python3 "$ROOT/bench.py" > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err" || exit 1 ;;
     stats)
         echo "[collect] kernel stats, bench.py"
+        rm -rf "$OUT/stats_bench"
         timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_bench" --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/stats_bench.log" 2>&1 || exit 1 ;;
     pmc_sparse)
         S="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
@@ -37,6 +39,7 @@ for part in $PARTS; do
     stats_dense)
         for mp in lists dense csr; do
             echo "[collect] kernel stats, bench_dense --mask-path $mp"
+            rm -rf "$OUT/stats_dense_$mp"
             timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_dense_$mp" --output-format csv -- python3 "$ROOT/benchmarks/bench_dense.py" --mask-path $mp > "$OUT/stats_dense_$mp.log" 2>&1 || exit 1
         done ;;
     pmc_dense)
