@@ -87,7 +87,7 @@ def main():
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 10 * 1e3
         line = {"world": world, "entries": g.nnz, "remote_entry_frac": round(remote, 3), "n_halo": n_halo,
-                "exchange_MB_per_direction_f32": round(n_halo * 288 / 1e6), "replicated_input_MB": round(n_halo * F * 4 / 1e6),
+                "exchange_MB_forward_f32": round(n_halo * 256 / 1e6), "exchange_MB_backward_f32": round(n_halo * 288 / 1e6), "replicated_input_MB": round(n_halo * F * 4 / 1e6),
                 "replicate_step_ms": round(ms, 3), "edges_per_s_per_gpu": round(g.nnz / ms * 1e3)}
         if world > 1:
             pe = gdist.PartitionedGraph(g, _LoopbackPeers(n_own, n_halo, dev), part, 0)

@@ -2,6 +2,8 @@
 # Collects the rocprofv3 evidence of one round on the GPU box:  bash profiles/collect.sh <tag> [part ...]
 # Parts (default: all): bench  stats  pmc_sparse  stats_dense  pmc_dense  pmc_bnf
 # Everything lands in gpurun_out/<tag>_prof/; profiles/summarize.py turns it into the files kept under profiles/.
+# gpurun merges what a run wrote into the local gpurun_out/ and deletes nothing there: remove the local
+# gpurun_out/<tag>_prof before collecting a part again, or the summaries mix two builds.
 # Counter passes run on their own (no tracing beside --pmc) and each within the per-block counter limits.
 set -u
 TAG=${1:?tag}; shift
