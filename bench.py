@@ -390,7 +390,7 @@ def main():
             partitioning = ("row-partitioned x%d, halo sources' input rows replicated at set-up and projected locally; per step one "
                             "RCCL all-reduce of the parameter gradients" % world)
         else:
-            partitioning = ("row-partitioned x%d, RCCL all-to-all of halo Wh/f2 rows (forward) and of their gradients (backward) every "
+            partitioning = ("row-partitioned x%d, RCCL all-to-all of halo Wh rows (forward) and of their gradients (backward) every "
                             "step%s, one all-reduce of the parameter gradients"
                             % (world, ", on a communication stream beside the sweeps over owned sources / owned columns" if dist_info["overlap"] else ""))
         line = {
