@@ -171,9 +171,9 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(uint32_t, r);
 }
 
-// Four consecutive elements c0..c0+3 of row `row` of a [rows, hd] table stored as fp32 or bf16.
+// Four consecutive elements c0..c0+3 of row `row` of a table with row stride `hd` elements, stored as fp32 or bf16.
 template <bool BF16>
-__device__ __forceinline__ float4 load_row4(const void *base, int64_t row, int hd, int c0) {
+__device__ __forceinline__ float4 load_row4(const void *base, int64_t row, int64_t hd, int c0) {
     if constexpr (BF16) {
         const uint2 u = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(base) + row * hd + c0);
         return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),

@@ -260,6 +260,7 @@ struct BwdNodeArgs {
     const float *dout, *out, *agg, *pos, *q, *f1, *lse;
     const float *bias;         // with out == nullptr: the pre-activation is agg + bias, read from registers instead of `out`
     float *g, *stats, *df1, *ws;
+    int64_t ldg, lds;          // row strides of g and stats in floats
     uint32_t *g16;             // optional bf16 copy of g (two values per dword), the table the per-source kernel gathers
     int activation, reduce;
     float slope;
@@ -279,6 +280,10 @@ __global__ __launch_bounds__(256) void gat_bwd_node_kernel(BwdNodeArgs a) {
     const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
     float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 biasv = a.bias ? *reinterpret_cast<const float4 *>(a.bias + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // g and the statistics as one record per row (stats = g + hd, common stride, a whole number of 16-byte pieces)
+    const int tail = (int)(a.ldg - HD);
+    const bool record = H % 4 == 0 && a.g && a.stats == a.g + HD && a.lds == a.ldg && tail >= 3 * H && tail <= 4 * G &&
+                        ((reinterpret_cast<uintptr_t>(a.f1) | reinterpret_cast<uintptr_t>(a.lse)) & 15) == 0;
     for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp; row < a.n; row += stride) {
         float4 gv;
         if (a.reduce == GATMI_REDUCE_MEAN) {
@@ -305,13 +310,34 @@ __global__ __launch_bounds__(256) void gat_bwd_node_kernel(BwdNodeArgs a) {
         }
         const float c = group_sum<LPH>(dot4(gv, ag));
         const float gp = group_sum<LPH>(dot4(gv, ps));
-        if (a.g) store_stream4(a.g + row * HD + sub * 4, gv);
+        if (a.g) store_stream4(a.g + row * a.ldg + sub * 4, gv);
         if (a.g16) *reinterpret_cast<uint2 *>(a.g16 + (row * HD + sub * 4) / 2) = make_uint2(pack_bf16x2(gv.x, gv.y), pack_bf16x2(gv.z, gv.w));
+        if (record) {
+            // [g | f1 lse c | zeros] is one record of whole 128-byte lines: its tail goes out as 16-byte stores too
+            // (lane k of the row writes floats 4k..4k+3 of the tail), so the wave writes the lines of its rows whole
+            constexpr int NQ = H >= 4 ? H / 4 : 1;          // 16-byte pieces per statistic
+            const int piece = sub % NQ;
+            float4 cq;
+            cq.x = __shfl(c, (lane - sub) + (4 * piece + 0) * LPH, 64);
+            cq.y = __shfl(c, (lane - sub) + (4 * piece + 1) * LPH, 64);
+            cq.z = __shfl(c, (lane - sub) + (4 * piece + 2) * LPH, 64);
+            cq.w = __shfl(c, (lane - sub) + (4 * piece + 3) * LPH, 64);
+            if (4 * sub < tail) {
+                const int stat = sub / NQ;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (stat == 0) t = *reinterpret_cast<const float4 *>(a.f1 + row * H + 4 * piece);
+                else if (stat == 1) t = *reinterpret_cast<const float4 *>(a.lse + row * H + 4 * piece);
+                else if (stat == 2) t = cq;
+                store_stream4(a.stats + row * a.lds + 4 * sub, t);
+            }
+        }
         if (sub % LPH == 0) {
             const float qv = a.q[row * H + head];
-            a.stats[row * 3 * H + head] = a.f1[row * H + head];
-            a.stats[row * 3 * H + H + head] = a.lse[row * H + head];
-            a.stats[row * 3 * H + 2 * H + head] = c;
+            if (!record) {
+                a.stats[row * a.lds + head] = a.f1[row * H + head];
+                a.stats[row * a.lds + H + head] = a.lse[row * H + head];
+                a.stats[row * a.lds + 2 * H + head] = c;
+            }
             a.df1[row * H + head] = (1.0f - a.slope) * (gp - c * qv);
         }
         gsum = f4_add(gsum, gv);
@@ -343,6 +369,7 @@ struct BwdCscArgs {
     const int32_t *rowidx, *perm;
     const void *g;             // gathered destination rows of g, fp32 or bf16 (template parameter BF16)
     const float *stats, *feat, *f2, *df1, *a1, *a2;
+    int64_t ldg, lds;          // row strides of g (in elements of its type) and stats (floats)
     const float *la2, *lb2;    // with f2 == nullptr: f2_j = <feat_j, la2> + lb2, as the forward kernel formed it
     float *dfeat, *df2, *ws;
     float slope, coef_keep, feat_keep;
@@ -366,8 +393,8 @@ __device__ __forceinline__ void bwd_batch(SrcState &st, const BwdCscArgs &a, con
     for (int t = 0; t < U; ++t) i[t] = rp[t];
 #pragma unroll
     for (int t = 0; t < U; ++t) {
-        gv[t] = load_row4<BF16>(a.g, i[t], HD, sub * 4);
-        const float *s = a.stats + (int64_t)i[t] * 3 * H + head;
+        gv[t] = load_row4<BF16>(a.g, i[t], a.ldg, sub * 4);
+        const float *s = a.stats + (int64_t)i[t] * a.lds + head;
         f1v[t] = s[0];
         lsev[t] = s[H];
         cv[t] = s[2 * H];
@@ -530,12 +557,17 @@ template <int G, int LPH>
 static int launch_fwd(const FwdArgs &a, const int4 *split, int64_t n_split, bool save, bool drop, bool bf16, hipStream_t st) {
     const unsigned nb = blocks_for(a.n_items, G);
     if (nb) {
-        if (bf16 && save) launch_fwd_rows<G, LPH, true, false, true>(a, nb, st);
-        else if (bf16) launch_fwd_rows<G, LPH, false, false, true>(a, nb, st);
-        else if (save && drop) launch_fwd_rows<G, LPH, true, true, false>(a, nb, st);
-        else if (save) launch_fwd_rows<G, LPH, true, false, false>(a, nb, st);
-        else if (drop) launch_fwd_rows<G, LPH, false, true, false>(a, nb, st);
-        else launch_fwd_rows<G, LPH, false, false, false>(a, nb, st);
+        const int variant = (save ? 4 : 0) | (drop ? 2 : 0) | (bf16 ? 1 : 0);
+        switch (variant) {
+        case 0: launch_fwd_rows<G, LPH, false, false, false>(a, nb, st); break;
+        case 1: launch_fwd_rows<G, LPH, false, false, true>(a, nb, st); break;
+        case 2: launch_fwd_rows<G, LPH, false, true, false>(a, nb, st); break;
+        case 3: launch_fwd_rows<G, LPH, false, true, true>(a, nb, st); break;
+        case 4: launch_fwd_rows<G, LPH, true, false, false>(a, nb, st); break;
+        case 5: launch_fwd_rows<G, LPH, true, false, true>(a, nb, st); break;
+        case 6: launch_fwd_rows<G, LPH, true, true, false>(a, nb, st); break;
+        default: launch_fwd_rows<G, LPH, true, true, true>(a, nb, st); break;
+        }
         GATMI_LAUNCH_CHECK("gat_fwd");
     }
     if (n_split > 0) {
@@ -565,7 +597,8 @@ template <int G, int LPH>
 static int launch_bwd_csc(const BwdCscArgs &a, const int4 *split, int64_t n_split, bool drop, bool bf16, hipStream_t st) {
     const unsigned nb = blocks_for(a.n_items, G);
     if (nb) {
-        if (bf16) hipLaunchKernelGGL((gat_bwd_csc_kernel<G, LPH, false, true>), dim3(nb), dim3(256), 0, st, a);
+        if (bf16 && drop) hipLaunchKernelGGL((gat_bwd_csc_kernel<G, LPH, true, true>), dim3(nb), dim3(256), 0, st, a);
+        else if (bf16) hipLaunchKernelGGL((gat_bwd_csc_kernel<G, LPH, false, true>), dim3(nb), dim3(256), 0, st, a);
         else if (drop) hipLaunchKernelGGL((gat_bwd_csc_kernel<G, LPH, true, false>), dim3(nb), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gat_bwd_csc_kernel<G, LPH, false, false>), dim3(nb), dim3(256), 0, st, a);
         GATMI_LAUNCH_CHECK("gat_bwd_csc");
@@ -672,7 +705,6 @@ static int gat_fwd_impl(const char *name, int64_t n_dst, int32_t H, int32_t dp,
     const bool drop = coef_keep < 1.f || feat_keep < 1.f;
     GATMI_REQUIRE(feat_dtype == GATMI_DTYPE_F32 || feat_dtype == GATMI_DTYPE_BF16, GATMI_EUNSUPPORTED, "%s: feat_dtype %d", name, feat_dtype);
     const bool bf16 = feat_dtype == GATMI_DTYPE_BF16;
-    GATMI_REQUIRE(!(bf16 && drop), GATMI_EUNSUPPORTED, "%s: dropout is only built for fp32 source rows", name);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int4 *sp = reinterpret_cast<const int4 *>(split);
 #define X(g, l) if (G == g && LPH == l) return launch_fwd<g, l>(a, sp, n_split, save, drop, bf16, st);
@@ -749,7 +781,8 @@ extern "C" int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
                                   const float *dout, const float *out, const float *agg, const float *pos,
                                   const float *q, const float *f1, const float *lse, const float *bias,
                                   int32_t activation, int32_t reduce, float slope,
-                                  float *g, uint16_t *g16, float *stats, float *df1, float *dbias, float *ws, void *stream) {
+                                  float *g, int64_t ldg, uint16_t *g16, float *stats, int64_t lds, float *df1, float *dbias, float *ws,
+                                  void *stream) {
     int G, LPH;
     int rc = check_shape(H, dp, &G, &LPH);
     if (rc) return rc;
@@ -763,7 +796,9 @@ extern "C" int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
     GATMI_REQUIRE_ALIGNED(g); GATMI_REQUIRE_ALIGNED(ws);
     BwdNodeArgs a;
     a.n = n_dst; a.dout = dout; a.out = out; a.bias = out ? nullptr : bias; a.agg = agg; a.pos = pos; a.q = q; a.f1 = f1; a.lse = lse;
-    a.g = g; a.g16 = reinterpret_cast<uint32_t *>(g16); a.stats = stats; a.df1 = df1; a.ws = ws;
+    GATMI_REQUIRE((!g || (ldg >= (int64_t)H * dp && ldg % 4 == 0)) && lds >= 3 * (int64_t)H, GATMI_EINVAL,
+                  "gat_bwd_node: row strides ldg=%lld (>= hd, multiple of 4) lds=%lld (>= 3H)", (long long)ldg, (long long)lds);
+    a.g = g; a.ldg = ldg; a.g16 = reinterpret_cast<uint32_t *>(g16); a.stats = stats; a.lds = lds; a.df1 = df1; a.ws = ws;
     a.activation = activation; a.reduce = reduce; a.slope = slope;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X(gg, l) if (G == gg && LPH == l) return launch_bwd_node<gg, l>(a, dbias, st);
@@ -780,7 +815,7 @@ extern "C" size_t gatmi_gat_bwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp
 extern "C" int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
                                  const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                                  const int32_t *rowidx, const int32_t *perm,
-                                 const void *g, int32_t g_dtype, const float *stats, const float *feat, const float *f2,
+                                 const void *g, int32_t g_dtype, int64_t ldg, const float *stats, int64_t lds, const float *feat, const float *f2,
                                  const float *logit_a2, const float *logit_b2,
                                  const float *df1, const float *a1, const float *a2,
                                  float slope, float coef_keep, float feat_keep, uint64_t seed,
@@ -803,13 +838,14 @@ extern "C" int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
     BwdCscArgs a;
     a.items = reinterpret_cast<const int4 *>(items);
     a.n_items = n_items; a.rowidx = rowidx; a.perm = perm;
-    a.g = g; a.stats = stats; a.feat = feat; a.f2 = f2; a.la2 = logit_a2; a.lb2 = logit_b2; a.df1 = df1; a.a1 = a1; a.a2 = a2;
+    GATMI_REQUIRE(ldg >= (int64_t)H * dp && ldg % 4 == 0 && lds >= 3 * (int64_t)H, GATMI_EINVAL,
+                  "gat_bwd_csc: row strides ldg=%lld (>= hd, multiple of 4) lds=%lld (>= 3H)", (long long)ldg, (long long)lds);
+    a.g = g; a.ldg = ldg; a.stats = stats; a.lds = lds; a.feat = feat; a.f2 = f2; a.la2 = logit_a2; a.lb2 = logit_b2; a.df1 = df1; a.a1 = a1; a.a2 = a2;
     a.dfeat = dfeat; a.df2 = df2; a.ws = ws;
     a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
     const bool drop = coef_keep < 1.f || feat_keep < 1.f;
     GATMI_REQUIRE(g_dtype == GATMI_DTYPE_F32 || g_dtype == GATMI_DTYPE_BF16, GATMI_EUNSUPPORTED, "gat_bwd_csc: g_dtype %d", g_dtype);
     const bool bf16 = g_dtype == GATMI_DTYPE_BF16;
-    GATMI_REQUIRE(!(bf16 && drop), GATMI_EUNSUPPORTED, "gat_bwd_csc: dropout is only built for fp32 rows");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int4 *sp = reinterpret_cast<const int4 *>(split);
 #define X(gg, l) if (G == gg && LPH == l) return launch_bwd_csc<gg, l>(a, sp, n_split, drop, bf16, st);

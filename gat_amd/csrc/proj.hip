@@ -33,6 +33,7 @@ struct GemmArgs {
     int Nc;
     float *C;         // [n, Nc], row stride ldc
     int64_t ldc;
+    uint32_t *C16;    // optional second copy of C in bf16, [n, Nc] contiguous (Nc % 4 == 0), two values per dword
     int accumulate;
     const float *cbias;  // [Nc] added to C, or null
     // fused logit halves (only when the whole row is inside one column tile)
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             }
             *reinterpret_cast<float4 *>(cp) = v;
+            if (g.C16) *reinterpret_cast<uint2 *>(g.C16 + (row * g.Nc + col) / 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
         } else {
             const float vv[4] = {v.x, v.y, v.z, v.w};
             for (int t = 0; t < 4 && col + t < g.Nc; ++t) cp[t] = g.accumulate ? cp[t] + vv[t] : vv[t];
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(64 * kResWaves) void proj_resident_kernel(GemmArgs 
             if (row < g.n && col < g.Nc) {
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 store_stream4(g.C + row * g.ldc + col, v);
+                if (g.C16) *reinterpret_cast<uint2 *>(g.C16 + (row * g.Nc + col) / 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -825,7 +828,7 @@ extern "C" int gatmi_proj_bwd_params_csr(const int64_t *xt_rowptr, const int32_t
 extern "C" int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t ldx,
                               const float *W, const float *a1, const float *a2,
                               const float *b1, const float *b2, int32_t H, int32_t dp,
-                              float *Wh, float *f1, float *f2,
+                              float *Wh, uint16_t *Wh16, float *f1, float *f2,
                               const float *W_res, const float *b_res, float *res_out, void *stream) {
     int G, LPH;
     int rc = check_shape(H, dp, &G, &LPH);
@@ -836,10 +839,11 @@ extern "C" int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t l
     const bool logits = f1 || f2;
     GATMI_REQUIRE(!logits || (f1 && f2 && a1 && a2 && b1 && b2), GATMI_EINVAL, "proj_fwd: f1, f2, a1, a2, b1, b2 go together");
     GATMI_REQUIRE((W_res == nullptr) == (res_out == nullptr), GATMI_EINVAL, "proj_fwd: W_res and res_out go together");
-    GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(a1); GATMI_REQUIRE_ALIGNED(a2); GATMI_REQUIRE_ALIGNED(res_out);
+    GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(a1); GATMI_REQUIRE_ALIGNED(a2); GATMI_REQUIRE_ALIGNED(res_out); GATMI_REQUIRE_ALIGNED(Wh16);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int hd = H * dp;
     GemmArgs g{};
+    g.C16 = reinterpret_cast<uint32_t *>(Wh16);
     g.A = X; g.n = n; g.K = f_in; g.lda = ldx;
     g.B = W; g.sbk = hd; g.sbc = 1; g.Nc = hd;
     g.C = Wh; g.ldc = hd; g.accumulate = 0; g.cbias = nullptr;

@@ -374,15 +374,15 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         f2 = ops._new((n_src if cfg.storage == "bf16" else n_proj, H), x)
         f1 = ops._new((n_proj, H), x)
         b2c = b2.reshape(H).contiguous()
-        _lib.call("gatmi_proj_fwd", ptr(x), n_proj, F, x.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1.contiguous()),
-                  ptr(b2c), H, dp, ptr(feat), ptr(f1), ptr(f2), None, None, None, st)
         bf16 = cfg.storage == "bf16"
         gtab, gdt = feat, _lib.DTYPE_F32
         if bf16:
-            # bf16 mode: the gathered table and therefore the halo rows on the wire are bf16 (half the
-            # forward exchange); the fp32 rows stay for the backward sweep and the parameter gradients
+            # bf16 mode: the gathered table (a second store of the projection's epilogue) and therefore the halo
+            # rows on the wire are bf16 (half the forward exchange); the fp32 rows stay for the backward sweep and
+            # the parameter gradients
             gtab, gdt = torch.empty((n_src, hd), dtype=torch.bfloat16, device=x.device), _lib.DTYPE_BF16
-            _lib.call("gatmi_to_bf16", ptr(feat), n_proj * hd, ptr(gtab), st)
+        _lib.call("gatmi_proj_fwd", ptr(x), n_proj, F, x.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1.contiguous()),
+                  ptr(b2c), H, dp, ptr(feat), ptr(gtab) if bf16 else None, ptr(f1), ptr(f2), None, None, None, st)
         ticket = None
         if not replicate:
             # fp32: only the Wh rows travel, the receiving sweep forms <Wh_j, a2> + b2 from them; bf16 rows
@@ -442,9 +442,13 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         else:
             dout = ops._pad_last(dout.reshape(n, H, D), D, dp).reshape(n, hd)
         bf16 = cfg.storage == "bf16"
-        g = None if bf16 else ops._new((n, hd), x)
         g16 = torch.empty((n, hd), dtype=torch.bfloat16, device=x.device) if bf16 else None
-        stats = ops._new((n, 3 * H), x)
+        if bf16:
+            g, stats = None, ops._new((n, 3 * H), x)
+        else:
+            rec = ops._new((n, ops._record_width(H, dp)), x)    # [g | f1 lse c | pad] per row: one gather per entry
+            g, stats = rec[:, :hd], rec[:, hd:hd + 3 * H]
+        ldg, lds = (hd if bf16 else g.stride(0)), stats.stride(0)
         if replicate:
             # halo rows are no destinations here: their logit gradient df1 belongs to their owner
             df1 = torch.zeros((n_src, H), dtype=torch.float32, device=x.device)
@@ -453,7 +457,7 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         dbias = ops._new((hd,), x)
         ws = ops._new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x)
         _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), None, ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse), ptr(biasp),
-                  ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, ptr(g), ptr(g16), ptr(stats), ptr(df1), ptr(dbias), ptr(ws), st)
+                  ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, ptr(g), ldg, ptr(g16), ptr(stats), lds, ptr(df1), ptr(dbias), ptr(ws), st)
         dfeat = ops._new((n_src, hd), x)
         df2 = ops._new((n_src, H), x)
         ws2 = None
@@ -466,8 +470,8 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             if len(items) == 0:
                 return
             _lib.call("gatmi_gat_bwd_csc", n_src, H, dp, ptr(items), len(items), ptr(split) if len(split) else None, len(split),
-                      ptr(graph.rowidx), ptr(graph.perm), ptr(g16 if bf16 else g), _lib.DTYPE_BF16 if bf16 else _lib.DTYPE_F32,
-                      ptr(stats), ptr(feat), *half, ptr(df1) if replicate else None, ptr(a1p) if replicate else None,
+                      ptr(graph.rowidx), ptr(graph.perm), ptr(g16 if bf16 else g), _lib.DTYPE_BF16 if bf16 else _lib.DTYPE_F32, ldg,
+                      ptr(stats), lds, ptr(feat), *half, ptr(df1) if replicate else None, ptr(a1p) if replicate else None,
                       ptr(a2p) if replicate else None,
                       cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dfeat), ptr(df2), ptr(ws2), st)
         if replicate:

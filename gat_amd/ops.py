@@ -53,13 +53,21 @@ class _Cfg:
     __slots__ = ("H", "D", "dp", "activation", "reduce", "slope", "coef_keep", "feat_keep", "seed", "storage", "mask_path")
 
 
+def _record_width(H, dp):
+    """Floats per row of the [g | f1 lse c | pad] records the backward kernels exchange: whole 128-byte lines."""
+    return (H * dp + 3 * H + 31) // 32 * 32
+
+
 def _new(shape, like, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
-def _project(x2d, W, a1, a2, b1, b2, cfg, W_res=None, b_res=None):
+def _project(x2d, W, a1, a2, b1, b2, cfg, W_res=None, b_res=None, Wh16_out=None):
     """K1: Wh = X.W (+ f1, f2) on [n, F] rows (dense tensor or SparseFeatures).  Returns padded
-    parameter views and outputs."""
+    parameter views and outputs.  Wh16_out: a list that receives an [n, hd] bfloat16 copy of Wh written by
+    the projection's epilogue (dense X only).  It is allocated here, after the fp32 outputs: the forward
+    kernel gathers from it and from the f2 table, and with the allocations the other way round it measured
+    15 % slower at the benchmark size."""
     n, F = x2d.shape
     sparse_x = isinstance(x2d, SparseFeatures)
     if sparse_x and W_res is not None:
@@ -79,12 +87,16 @@ def _project(x2d, W, a1, a2, b1, b2, cfg, W_res=None, b_res=None):
         Wrp = _pad_last(W_res.reshape(F, H, D), D, dp).reshape(F, hd)
         brp = _pad_last(b_res.reshape(H, D), D, dp).reshape(hd)
         res = _new((n, hd), x2d)
+    Wh16 = None
+    if Wh16_out is not None and not sparse_x:
+        Wh16 = torch.empty((n, hd), dtype=torch.bfloat16, device=Wh.device)
+        Wh16_out.append(Wh16)
     if sparse_x:
         _lib.call("gatmi_proj_fwd_csr", ptr(x2d.rowptr), ptr(x2d.col), ptr(x2d.val), n, F, ptr(Wp), ptr(a1p), ptr(a2p),
                   ptr(b1c), ptr(b2c), H, dp, ptr(Wh), ptr(f1), ptr(f2), _lib.current_stream())
         return Wp, a1p, a2p, None, Wh, f1, f2, None
     _lib.call("gatmi_proj_fwd", ptr(x2d), n, F, x2d.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1c), ptr(b2c),
-              H, dp, ptr(Wh), ptr(f1), ptr(f2), ptr(Wrp), ptr(brp), ptr(res), _lib.current_stream())
+              H, dp, ptr(Wh), ptr(Wh16), ptr(f1), ptr(f2), ptr(Wrp), ptr(brp), ptr(res), _lib.current_stream())
     return Wp, a1p, a2p, Wrp, Wh, f1, f2, res
 
 
@@ -137,7 +149,8 @@ class SparseGATLayerFn(torch.autograd.Function):
         H, D, dp = cfg.H, cfg.D, cfg.dp
         hd = H * dp
         st = _lib.current_stream()
-        Wp, a1p, a2p, Wrp, Wh, f1, f2, res = _project(x, W, a1, a2, b1, b2, cfg, W_res, b_res)
+        made16 = [] if cfg.storage == "bf16" else None
+        Wp, a1p, a2p, Wrp, Wh, f1, f2, res = _project(x, W, a1, a2, b1, b2, cfg, W_res, b_res, made16)
         # fp32 rows: the kernels form the source half of the logits, <Wh_j, a2> + b2, from the rows they gather
         # (b2c given, no f2 table); bf16 rows would add their rounding to the logits, so that mode gathers the table
         b2c = _f32(b2).reshape(H).contiguous() if cfg.storage != "bf16" else None
@@ -156,8 +169,12 @@ class SparseGATLayerFn(torch.autograd.Function):
             ws = _new((_lib.lib.gatmi_gat_fwd_ws_floats(graph.n_slots_csr, H, dp),), x)
         feat, fdt = Wh, _lib.DTYPE_F32
         if cfg.storage == "bf16":
-            feat, fdt = torch.empty((n, hd), dtype=torch.bfloat16, device=x.device), _lib.DTYPE_BF16
-            _lib.call("gatmi_to_bf16", ptr(Wh), n * hd, ptr(feat), st)
+            if made16:
+                feat = made16[0]                             # written by the projection's epilogue
+            else:
+                feat = torch.empty((n, hd), dtype=torch.bfloat16, device=Wh.device)
+                _lib.call("gatmi_to_bf16", ptr(Wh), n * hd, ptr(feat), st)
+            fdt = _lib.DTYPE_BF16
         _lib.call("gatmi_gat_fwd", n, H, dp, ptr(graph.items_csr), len(graph.items_csr),
                   ptr(graph.split_csr) if len(graph.split_csr) else None, len(graph.split_csr),
                   ptr(graph.col), ptr(feat), fdt, ptr(f1), ptr(f2), ptr(a2p) if f2 is None else None, ptr(b2c), ptr(biasp), ptr(res),
@@ -187,15 +204,22 @@ class SparseGATLayerFn(torch.autograd.Function):
         else:
             dout = _pad_last(dout.reshape(n, H, D), D, dp).reshape(n, hd)
         bf16 = cfg.storage == "bf16"
-        g = _new((n, hd), x) if (not bf16 or ctx.has_res) else None      # the residual branch reads fp32 g
         g16 = torch.empty((n, hd), dtype=torch.bfloat16, device=x.device) if bf16 else None
-        stats = _new((n, 3 * H), x)
+        if bf16 or ctx.has_res:
+            g = _new((n, hd), x) if ctx.has_res else None                # the residual branch reads contiguous fp32 g
+            stats = _new((n, 3 * H), x)
+        else:
+            # one record per destination row, [g | f1 lse c]: the per-source kernel's two gathers per entry
+            # read one contiguous piece of memory
+            rec = _new((n, _record_width(H, dp)), x)
+            g, stats = rec[:, :hd], rec[:, hd:hd + 3 * H]
+        ldg, lds = (g.stride(0) if g is not None else hd), stats.stride(0)
         df1 = _new((n, H), x)
         dbias = _new((hd,), x)
         ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x)
         # without a residual the pre-activation is agg + bias: the kernel then does not read `out`
         _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out) if ctx.has_res else None, ptr(agg), ptr(pos), ptr(q), ptr(f1),
-                  ptr(lse), ptr(biasp), _ACT[cfg.activation], _RED[cfg.reduce], cfg.slope, ptr(g), ptr(g16), ptr(stats), ptr(df1),
+                  ptr(lse), ptr(biasp), _ACT[cfg.activation], _RED[cfg.reduce], cfg.slope, ptr(g), ldg, ptr(g16), ptr(stats), lds, ptr(df1),
                   ptr(dbias), ptr(ws), st)
         gtab, gdt = (g16, _lib.DTYPE_BF16) if bf16 else (g, _lib.DTYPE_F32)
         dWh = _new((n, hd), x)
@@ -205,7 +229,7 @@ class SparseGATLayerFn(torch.autograd.Function):
             ws2 = _new((_lib.lib.gatmi_gat_bwd_ws_floats(graph.n_slots_csc, H, dp),), x)
         _lib.call("gatmi_gat_bwd_csc", n, H, dp, ptr(graph.items_csc), len(graph.items_csc),
                   ptr(graph.split_csc) if len(graph.split_csc) else None, len(graph.split_csc),
-                  ptr(graph.rowidx), ptr(graph.perm), ptr(gtab), gdt, ptr(stats), ptr(Wh), ptr(f2), ptr(a2p) if f2 is None else None, ptr(b2c),
+                  ptr(graph.rowidx), ptr(graph.perm), ptr(gtab), gdt, hd if bf16 else ldg, ptr(stats), lds, ptr(Wh), ptr(f2), ptr(a2p) if f2 is None else None, ptr(b2c),
                   ptr(df1), ptr(a1p), ptr(a2p), cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dWh), ptr(df2), ptr(ws2), st)
         dx, dW, da1, da2, db1, db2, dWr = _project_backward(x, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
         db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None
@@ -337,7 +361,7 @@ class DenseGATLayerFn(torch.autograd.Function):
         dbias = _new((hd,), x2)
         ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x2)
         _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out) if ctx.has_res else None, ptr(agg), ptr(pos), ptr(q), ptr(f1),
-                  ptr(lse), ptr(biasp), _ACT[cfg.activation], _lib.REDUCE_CONCAT, cfg.slope, ptr(g), None, ptr(stats), ptr(df1),
+                  ptr(lse), ptr(biasp), _ACT[cfg.activation], _lib.REDUCE_CONCAT, cfg.slope, ptr(g), hd, None, ptr(stats), 3 * H, ptr(df1),
                   ptr(dbias), ptr(ws), st)
         dWh = _new((n, hd), x2)
         df2 = _new((n, H), x2)
@@ -380,8 +404,6 @@ def make_cfg(H, D, activation="elu", reduce="concat", coef_drop=0.0, in_drop=0.0
     c.seed = int(seed)
     if storage not in ("f32", "bf16"):
         raise ValueError("storage must be 'f32' or 'bf16'")
-    if storage == "bf16" and (c.coef_keep < 1.0 or c.feat_keep < 1.0):
-        raise ValueError("bf16 storage of the gathered tables is built without in-kernel dropout")
     c.storage = storage
     if mask_path not in ("auto", "lists", "dense"):
         raise ValueError("mask_path must be 'auto', 'lists' or 'dense'")
@@ -446,7 +468,7 @@ class BnfAggregateFn(torch.autograd.Function):
         df1 = _new((n, H), xp)
         ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, fp),), xp)
         _lib.call("gatmi_gat_bwd_node", n, H, fp, ptr(G), None, ptr(t2n), ptr(t2pos), ptr(q), ptr(f1), ptr(lse), None,
-                  _lib.ACT_IDENTITY, _lib.REDUCE_CONCAT, slope, ptr(g), None, ptr(stats), ptr(df1), None, ptr(ws), st)
+                  _lib.ACT_IDENTITY, _lib.REDUCE_CONCAT, slope, ptr(g), H * fp, None, ptr(stats), 3 * H, ptr(df1), None, ptr(ws), st)
         dx = _new((n, fp), xp)
         dA = _new((B, N, N), xp)
         df2 = _new((n, H), xp)

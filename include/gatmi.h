@@ -130,12 +130,14 @@ int gatmi_halo_plan(int32_t nparts, int32_t rank, const int64_t *part, int64_t n
 /* Feature projection with the logit halves fused: replaces utils/layers.py:11 (seq_fts = X.W,
  * no bias), :14 (f_1 = seq_fts.a1 + b1) and :15 (f_2 = seq_fts.a2 + b2) for all H heads at once.
  *   X [n, f_in] (row stride ldx floats), W [f_in, hd], a1,a2 [hd], b1,b2 [H]
- *   Wh [n, hd], f1,f2 [n, H].  W_res/b_res/res_out: optional second projection of the same X
- *   (residual branch, utils/layers.py:30), NULL to skip. */
+ *   Wh [n, hd], f1,f2 [n, H].  Wh16 [n, hd]: optional second copy of Wh in bf16 (round to nearest even,
+ *   written from the same registers), the gather-side table of GATMI_DTYPE_BF16; NULL to skip.
+ *   W_res/b_res/res_out: optional second projection of the same X (residual branch, utils/layers.py:30),
+ *   NULL to skip. */
 int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t ldx,
                    const float *W, const float *a1, const float *a2,
                    const float *b1, const float *b2, int32_t H, int32_t dp,
-                   float *Wh, float *f1, float *f2,
+                   float *Wh, uint16_t *Wh16, float *f1, float *f2,
                    const float *W_res, const float *b_res, float *res_out, void *stream);
 
 /* Parameter gradients of the projection: dW = X^T . dWh [f_in, hd]; and, when Wh != NULL,
@@ -233,9 +235,11 @@ int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
                           float *out, float *agg, float *pos, float *lse, float *q, void *stream);
 
 /* Backward, per-destination part (no gather).  From dOut and the saved forward tensors:
- *   g [n_dst, hd]    = dOut * activation'(out)              (dOut / H per head for mean);
- *       g16: the same rows in bf16 for gatmi_gat_bwd_csc's gather; either of g / g16 may be NULL
- *   stats [n_dst, 3, H] = {f1, lse, c}, c = <g, agg> per head
+ *   g [n_dst, hd]    = dOut * activation'(out)              (dOut / H per head for mean), row stride ldg floats;
+ *       g16: the same rows in bf16 (contiguous) for gatmi_gat_bwd_csc's gather; either of g / g16 may be NULL
+ *   stats [n_dst, 3, H] = {f1, lse, c}, c = <g, agg> per head, row stride lds floats.  g and stats may
+ *       interleave in one buffer of [n_dst, hd + 3H] records (ldg = lds = hd + 3H, stats = g + hd): the two
+ *       gathers per entry of gatmi_gat_bwd_csc then read one contiguous record
  *   df1 [n_dst, H]   = (1 - slope) * (<g, pos> - c * q)     = sum_j dlogit_ij  (gradient of f_1)
  *   dbias [hd]       = sum_i g (NULL to skip);  dresid is g itself.
  *   activation': ELU / ReLU need the layer's pre-activation.  Pass `out` (the saved output; required
@@ -247,12 +251,14 @@ int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
                        const float *dout, const float *out, const float *agg, const float *pos,
                        const float *q, const float *f1, const float *lse, const float *bias,
                        int32_t activation, int32_t reduce, float slope,
-                       float *g, uint16_t *g16, float *stats, float *df1, float *dbias, float *ws, void *stream);
+                       float *g, int64_t ldg, uint16_t *g16, float *stats, int64_t lds, float *df1, float *dbias, float *ws,
+                       void *stream);
 
 /* Backward, per-source part: transposed SpMM + SDDMM over the CSC structure.
  *   items/split: gatmi_work_items of colptr; rowidx: CSC destination ids; perm: CSR position of
  *   each CSC entry (only read when coef_keep < 1, may be NULL otherwise)
- *   g [n_dst, hd] (fp32 or bf16) and stats [n_dst, 3, H] from gatmi_gat_bwd_node
+ *   g [n_dst, hd] (fp32 or bf16; row stride ldg elements) and stats [n_dst, 3, H] (row stride lds floats)
+ *       from gatmi_gat_bwd_node
  *   dfeat [n_src, hd] = sum_i alpha_ij g_i  (+ df1_j a1 + df2_j a2 when a1 != NULL: then dfeat
  *       is the full gradient of Wh = seq_fts and df1 [n_src, H] must be given)
  *   df2 [n_src, H]    = sum_i dlogit_ij
@@ -263,7 +269,7 @@ size_t gatmi_gat_bwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp);
 int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
                       const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                       const int32_t *rowidx, const int32_t *perm,
-                      const void *g, int32_t g_dtype, const float *stats, const float *feat, const float *f2,
+                      const void *g, int32_t g_dtype, int64_t ldg, const float *stats, int64_t lds, const float *feat, const float *f2,
                       const float *logit_a2, const float *logit_b2,
                       const float *df1, const float *a1, const float *a2,
                       float slope, float coef_keep, float feat_keep, uint64_t seed,

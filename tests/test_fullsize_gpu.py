@@ -65,19 +65,19 @@ def test_gradient_checksums_and_determinism(big):
         gg, stats, df1, dbias = new(n, hd), new(n, 3 * H), new(n, H), new(hd)
         wsn = new(_lib.lib.gatmi_gat_bwd_node_ws_floats(H, D))
         _lib.call("gatmi_gat_bwd_node", n, H, D, ptr(dout), ptr(out), ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse), None,
-                  _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(gg), None, ptr(stats), ptr(df1), ptr(dbias), ptr(wsn), st)
+                  _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(gg), hd, None, ptr(stats), 3 * H, ptr(df1), ptr(dbias), ptr(wsn), st)
         # the same from the pre-activation agg + bias instead of the saved output (the form the layers use)
         gg2, stats2, df12, dbias2 = new(n, hd), new(n, 3 * H), new(n, H), new(hd)
         _lib.call("gatmi_gat_bwd_node", n, H, D, ptr(dout), None, ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse),
-                  ptr(p["bias"].reshape(-1).contiguous()), _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(gg2), None, ptr(stats2),
-                  ptr(df12), ptr(dbias2), ptr(wsn), st)
+                  ptr(p["bias"].reshape(-1).contiguous()), _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(gg2), hd, None, ptr(stats2),
+                  3 * H, ptr(df12), ptr(dbias2), ptr(wsn), st)
         # (the saved-output form computes ELU' as out + 1, which loses relative accuracy where out is close to -1)
         assert torch.allclose(gg2, gg, rtol=1e-5, atol=2e-7 * float(gg.abs().max()))
         assert torch.allclose(df12, df1, rtol=1e-3, atol=1e-5 * float(df1.abs().max()))
         dfeat, df2 = new(n, hd), new(n, H)
         wsb = new(_lib.lib.gatmi_gat_bwd_ws_floats(g.n_slots_csc, H, D))
         _lib.call("gatmi_gat_bwd_csc", n, H, D, ptr(g.items_csc), len(g.items_csc), ptr(g.split_csc), len(g.split_csc),
-                  ptr(g.rowidx), None, ptr(gg), _lib.DTYPE_F32, ptr(stats), ptr(Wh), ptr(f2), None, None, None, None, None,
+                  ptr(g.rowidx), None, ptr(gg), _lib.DTYPE_F32, hd, ptr(stats), 3 * H, ptr(Wh), ptr(f2), None, None, None, None, None,
                   0.2, 1.0, 1.0, 0, ptr(dfeat), ptr(df2), ptr(wsb), st)
         outs.append((out, dfeat, df2, df1, dbias, gg))
     (out, dfeat, df2, df1, dbias, gg), second = outs

@@ -220,11 +220,11 @@ def test_source_logit_half_formed_from_the_rows_matches_the_table(H, D):
         g, stats, df1, dbias = new(n, hd), new(n, 3 * H), new(n, H), new(hd)
         wsn = new(_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp))
         _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), None, ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse), None,
-                  _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(g), None, ptr(stats), ptr(df1), ptr(dbias), ptr(wsn), st)
+                  _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(g), hd, None, ptr(stats), 3 * H, ptr(df1), ptr(dbias), ptr(wsn), st)
         dfeat, df2 = new(n, hd), new(n, H)
         wsb = new(max(1, _lib.lib.gatmi_gat_bwd_ws_floats(graph.n_slots_csc, H, dp)))
         _lib.call("gatmi_gat_bwd_csc", n, H, dp, ptr(graph.items_csc), len(graph.items_csc), ptr(graph.split_csc), len(graph.split_csc),
-                  ptr(graph.rowidx), None, ptr(g), _lib.DTYPE_F32, ptr(stats), ptr(Wh), *half, ptr(df1), ptr(a1p), ptr(a2p),
+                  ptr(graph.rowidx), None, ptr(g), _lib.DTYPE_F32, hd, ptr(stats), 3 * H, ptr(Wh), *half, ptr(df1), ptr(a1p), ptr(a2p),
                   0.2, 1.0, 1.0, 0, ptr(dfeat), ptr(df2), ptr(wsb), st)
         torch.cuda.synchronize()
         return {"out": out, "lse": lse, "q": q, "dfeat": dfeat, "df2": df2, "df1": df1}
