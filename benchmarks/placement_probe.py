@@ -39,13 +39,13 @@ def main():
     out, agg, pos, lse, q = new(n, hd), new(n, hd), new(n, hd), new(n, H), new(n, H)
     ws = new(max(1, _lib.lib.gatmi_gat_fwd_ws_floats(g.n_slots_csr, H, D)))
     _lib.call("gatmi_gat_fwd", n, H, D, ptr(g.items_csr), len(g.items_csr), ptr(g.split_csr), len(g.split_csr),
-              ptr(g.col), ptr(Wh), _lib.DTYPE_F32, ptr(f1), None, ptr(a2p), ptr(b2c), None, None,
+              ptr(g.col), ptr(Wh), _lib.DTYPE_F32, hd, ptr(f1), None, ptr(a2p), ptr(b2c), None, None,
               _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, 1.0, 1.0, 0, ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
     dout = synth.normal((n, hd), 8, dev)
     g0, stats0, df1, dbias = new(n, hd), new(n, 3 * H), new(n, H), new(hd)
     wsn = new(_lib.lib.gatmi_gat_bwd_node_ws_floats(H, D))
     _lib.call("gatmi_gat_bwd_node", n, H, D, ptr(dout), None, ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse), None,
-              _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(g0), hd, None, ptr(stats0), 3 * H, ptr(df1), ptr(dbias), ptr(wsn), st)
+              _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(g0), hd, None, 0, ptr(stats0), 3 * H, ptr(df1), ptr(dbias), ptr(wsn), st)
     del out, agg, pos, dout, x
     wsb = new(max(1, _lib.lib.gatmi_gat_bwd_ws_floats(g.n_slots_csc, H, D)))
     df2 = new(n, H)

@@ -37,7 +37,7 @@ _SIGNATURES = {
     "gatmi_work_items_phased": (c_int, [c_int64, P, P, c_int32, P, P, P]),
     "gatmi_partition_rows": (c_int, [c_int64, c_int32, P, c_int32, P]),
     "gatmi_halo_plan": (c_int, [c_int32, c_int32, P, c_int64, P, P, P, P, P]),
-    "gatmi_proj_fwd": (c_int, [P, c_int64, c_int32, c_int64, P, P, P, P, P, c_int32, c_int32, P, P, P, P, P, P, P, P]),
+    "gatmi_proj_fwd": (c_int, [P, c_int64, c_int32, c_int64, P, P, P, P, P, c_int32, c_int32, P, P, c_int64, P, P, P, P, P, P]),
     "gatmi_proj_bwd_ws_floats": (c_size_t, [c_int32, c_int32, c_int32]),
     "gatmi_proj_bwd_params": (c_int, [P, c_int64, c_int32, c_int64, P, P, P, P, c_int32, c_int32, P, P, P, P, P, P, P]),
     "gatmi_proj_bwd_input": (c_int, [P, c_int64, c_int32, P, c_int32, c_int32, P, c_int64, c_int, P]),
@@ -46,13 +46,14 @@ _SIGNATURES = {
     "gatmi_proj_bwd_params_csr": (c_int, [P, P, P, c_int64, c_int32, P, P, P, P, c_int32, c_int32, P, P, P, P, P, P, P]),
     "gatmi_gat_fwd_ws_floats": (c_size_t, [c_int64, c_int32, c_int32]),
     "gatmi_to_bf16": (c_int, [P, c_int64, P, P]),
-    "gatmi_gat_fwd": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, P, c_int32, P, P, P, P, P, P, c_int32, c_int32,
+    "gatmi_to_bf16_records": (c_int, [P, P, c_int64, c_int32, c_int32, c_int64, P, P]),
+    "gatmi_gat_fwd": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, P, c_int32, c_int64, P, P, P, P, P, P, c_int32, c_int32,
                               c_float, c_float, c_float, c_uint64, P, P, P, P, P, P, P]),
-    "gatmi_gat_fwd_noalloc": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, c_int64, P, P, c_int32, P, P, P, P, P, P,
+    "gatmi_gat_fwd_noalloc": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, c_int64, P, P, c_int32, c_int64, P, P, P, P, P, P,
                                       c_int32, c_int32, c_float, c_float, c_float, c_uint64, P, P, P, P, P, P]),
     "gatmi_gat_bwd_node_ws_floats": (c_size_t, [c_int32, c_int32]),
     "gatmi_gat_bwd_node": (c_int, [c_int64, c_int32, c_int32, P, P, P, P, P, P, P, P, c_int32, c_int32, c_float,
-                                   P, c_int64, P, P, c_int64, P, P, P, P]),
+                                   P, c_int64, P, c_int64, P, c_int64, P, P, P, P]),
     "gatmi_gat_bwd_ws_floats": (c_size_t, [c_int64, c_int32, c_int32]),
     "gatmi_gat_bwd_csc": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, P, P, c_int32, c_int64, P, c_int64, P, P, P, P, P, P, P,
                                   c_float, c_float, c_float, c_uint64, P, P, P, P]),

@@ -42,6 +42,7 @@ struct FwdArgs {
     int64_t n_items;
     const int32_t *col;
     const void *feat;          // gathered source rows, fp32 or bf16 (template parameter BF16)
+    int64_t ldf;               // their row stride, in elements of their type
     const float *f1, *f2, *bias, *resid;
     const float *la2, *lb2;    // with f2 == nullptr: f2_j = <feat_j, la2> + lb2, formed from the gathered row (kernels built with F2ROW)
     float *out, *agg, *pos, *lse, *q, *ws;
@@ -57,8 +58,9 @@ struct RowState {
 };
 
 // One batch of U neighbours of one row group.  F2ROW: the source half of the logit is not gathered
-// from a table but formed from the gathered row itself, f2_j = <feat_j, a2> + b2 per head (utils/layers.py:15):
-// one request per entry less, for four multiply-adds and a cross-lane step in the shadow of the row load.
+// from a table but comes with the gathered row: formed from it, f2_j = <feat_j, a2> + b2 per head
+// (utils/layers.py:15; fp32 rows: four multiply-adds and a cross-lane step in the shadow of the row load),
+// or read from the tail of the row's record (bf16 rows, whose rounding must stay out of the logits).
 template <int G, int LPH, int U, bool SAVE, bool DROP, bool BF16, bool F2ROW>
 __device__ __forceinline__ void fwd_batch(RowState &st, const FwdArgs &a, const int32_t *cp, int64_t epos,
                                           float f1v, float4 a2v, float b2h, int sub, int head) {
@@ -72,9 +74,11 @@ __device__ __forceinline__ void fwd_batch(RowState &st, const FwdArgs &a, const 
 #pragma unroll
     for (int t = 0; t < U; ++t) {
         if (!F2ROW) z[t] = f1v + a.f2[(int64_t)j[t] * H + head];
-        v[t] = load_row4<BF16>(a.feat, j[t], HD, sub * 4);
+        v[t] = load_row4<BF16>(a.feat, j[t], a.ldf, sub * 4);
+        // bf16 records: the exact fp32 f2 of the row sits behind its HD bf16 values, in the lines this gather fetches
+        if (F2ROW && BF16) z[t] = f1v + *reinterpret_cast<const float *>(reinterpret_cast<const uint16_t *>(a.feat) + (int64_t)j[t] * a.ldf + HD + 2 * head);
     }
-    if (F2ROW) {
+    if (F2ROW && !BF16) {
 #pragma unroll
         for (int t = 0; t < U; ++t) z[t] = f1v + (group_sum<LPH>(dot4(v[t], a2v)) + b2h);
     }
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
     const float f1v = a.f1[row * H + head];
     float4 a2v = make_float4(0.f, 0.f, 0.f, 0.f);
     float b2h = 0.f;
-    if (F2ROW) {
+    if (F2ROW && !BF16) {
         a2v = *reinterpret_cast<const float4 *>(a.la2 + sub * 4);
         if (a.lb2) b2h = a.lb2[head];
     }
@@ -261,6 +265,7 @@ struct BwdNodeArgs {
     const float *bias;         // with out == nullptr: the pre-activation is agg + bias, read from registers instead of `out`
     float *g, *stats, *df1, *ws;
     int64_t ldg, lds;          // row strides of g and stats in floats
+    int64_t ldg16;             // row stride of g16 in bf16 elements
     uint32_t *g16;             // optional bf16 copy of g (two values per dword), the table the per-source kernel gathers
     int activation, reduce;
     float slope;
@@ -281,9 +286,12 @@ __global__ __launch_bounds__(256) void gat_bwd_node_kernel(BwdNodeArgs a) {
     float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 biasv = a.bias ? *reinterpret_cast<const float4 *>(a.bias + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     // g and the statistics as one record per row (stats = g + hd, common stride, a whole number of 16-byte pieces)
-    const int tail = (int)(a.ldg - HD);
-    const bool record = H % 4 == 0 && a.g && a.stats == a.g + HD && a.lds == a.ldg && tail >= 3 * H && tail <= 4 * G &&
-                        ((reinterpret_cast<uintptr_t>(a.f1) | reinterpret_cast<uintptr_t>(a.lse)) & 15) == 0;
+    // (or, bf16: stats right behind the HD bf16 values of g16, strides equal in bytes)
+    const bool rec32 = a.g && a.stats == a.g + HD && a.lds == a.ldg;
+    const bool rec16 = a.g16 && a.stats == reinterpret_cast<float *>(a.g16 + HD / 2) && 2 * a.lds == a.ldg16;
+    const int tail = (int)(rec32 ? a.ldg - HD : a.lds - HD / 2);
+    const bool record = H % 4 == 0 && (rec32 || rec16) && tail >= 3 * H && tail <= 4 * G &&
+                        ((reinterpret_cast<uintptr_t>(a.f1) | reinterpret_cast<uintptr_t>(a.lse) | reinterpret_cast<uintptr_t>(a.stats)) & 15) == 0;
     for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp; row < a.n; row += stride) {
         float4 gv;
         if (a.reduce == GATMI_REDUCE_MEAN) {
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256) void gat_bwd_node_kernel(BwdNodeArgs a) {
         const float c = group_sum<LPH>(dot4(gv, ag));
         const float gp = group_sum<LPH>(dot4(gv, ps));
         if (a.g) store_stream4(a.g + row * a.ldg + sub * 4, gv);
-        if (a.g16) *reinterpret_cast<uint2 *>(a.g16 + (row * HD + sub * 4) / 2) = make_uint2(pack_bf16x2(gv.x, gv.y), pack_bf16x2(gv.z, gv.w));
+        if (a.g16) *reinterpret_cast<uint2 *>(a.g16 + (row * a.ldg16 + sub * 4) / 2) = make_uint2(pack_bf16x2(gv.x, gv.y), pack_bf16x2(gv.z, gv.w));
         if (record) {
             // [g | f1 lse c | zeros] is one record of whole 128-byte lines: its tail goes out as 16-byte stores too
             // (lane k of the row writes floats 4k..4k+3 of the tail), so the wave writes the lines of its rows whole
@@ -459,13 +467,8 @@ __global__ __launch_bounds__(256) void gat_bwd_csc_kernel(BwdCscArgs a) {
     if (a.f2) {
         f2v = a.f2[j * H + head];
     } else {
-        // the same expression, on the same numbers, as gat_fwd_kernel<..., F2ROW>: a forward pass that
-        // gathered the bf16 table saw this row rounded to bf16
-        float4 w = whj;
-        if (BF16) {
-            const uint32_t lo = pack_bf16x2(w.x, w.y), hi = pack_bf16x2(w.z, w.w);
-            w = make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u));
-        }
+        // the same expression, on the same numbers, as gat_fwd_kernel<..., F2ROW> on fp32 rows
+        const float4 w = whj;
         f2v = group_sum<LPH>(dot4(w, *reinterpret_cast<const float4 *>(a.la2 + sub * 4))) + (a.lb2 ? a.lb2[head] : 0.f);
     }
     if (DROP) {
@@ -549,7 +552,7 @@ static inline unsigned blocks_for(int64_t n_groups, int G) {
 
 template <int G, int LPH, bool SAVE, bool DROP, bool BF16>
 static void launch_fwd_rows(const FwdArgs &a, unsigned nb, hipStream_t st) {
-    if (a.la2) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, SAVE, DROP, BF16, true>), dim3(nb), dim3(256), 0, st, a);
+    if (!a.f2) hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, SAVE, DROP, BF16, true>), dim3(nb), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gat_fwd_kernel<G, LPH, SAVE, DROP, BF16, false>), dim3(nb), dim3(256), 0, st, a);
 }
 
@@ -651,6 +654,41 @@ __global__ __launch_bounds__(256) void to_bf16_kernel(const float4 *src, int64_t
 }
 }  // namespace gatmi
 
+namespace gatmi {
+// Row records [hd bf16 | f2: H fp32 | pad] of the bf16 gather table (ld16 bf16 elements apart); pad is left alone.
+__global__ __launch_bounds__(256) void to_bf16_records_kernel(const float *src, const float *f2, int64_t n, int hd, int H, int64_t ld16, uint16_t *dst) {
+    const int per_row = hd / 4 + H;                    // 8-byte pieces of Wh, then 4-byte f2 values
+    const int64_t total = n * per_row;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / per_row;
+        const int k = (int)(e - row * per_row);
+        if (k < hd / 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + row * hd + 4 * k);
+            *reinterpret_cast<uint2 *>(dst + row * ld16 + 4 * k) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        } else {
+            *reinterpret_cast<float *>(dst + row * ld16 + hd + 2 * (k - hd / 4)) = f2[row * H + (k - hd / 4)];
+        }
+    }
+}
+}  // namespace gatmi
+
+extern "C" int gatmi_to_bf16_records(const float *src, const float *f2, int64_t n, int32_t H, int32_t dp, int64_t ld16,
+                                     uint16_t *dst, void *stream) {
+    int G, LPH;
+    int rc = check_shape(H, dp, &G, &LPH);
+    if (rc) return rc;
+    const int hd = H * dp;
+    GATMI_REQUIRE(n >= 0 && ld16 >= (int64_t)hd + 2 * H && ld16 % 4 == 0, GATMI_EINVAL, "to_bf16_records: n=%lld ld16=%lld (>= hd + 2H, multiple of 4)", (long long)n, (long long)ld16);
+    if (n == 0) return GATMI_OK;
+    GATMI_REQUIRE(src && f2 && dst, GATMI_EINVAL, "to_bf16_records: null pointer");
+    GATMI_REQUIRE_ALIGNED(src); GATMI_REQUIRE_ALIGNED(dst);
+    const int64_t total = n * (hd / 4 + H);
+    const unsigned nb = (unsigned)std::min<int64_t>(8192, (total + 255) / 256);
+    hipLaunchKernelGGL(to_bf16_records_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, f2, n, hd, H, ld16, dst);
+    GATMI_LAUNCH_CHECK("to_bf16_records");
+    return GATMI_OK;
+}
+
 extern "C" int gatmi_to_bf16(const float *src, int64_t n_elems, uint16_t *dst, void *stream) {
     GATMI_REQUIRE(n_elems >= 0 && n_elems % 4 == 0, GATMI_EINVAL, "to_bf16: element count %lld must be a non-negative multiple of 4", (long long)n_elems);
     if (n_elems == 0) return GATMI_OK;
@@ -671,7 +709,7 @@ extern "C" size_t gatmi_gat_fwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp
 
 static int gat_fwd_impl(const char *name, int64_t n_dst, int32_t H, int32_t dp,
                         const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
-                        const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
+                        const int32_t *col, const void *feat, int32_t feat_dtype, int64_t ldfeat, const float *f1, const float *f2,
                         const float *logit_a2, const float *logit_b2,
                         const float *bias, const float *resid, int32_t activation, int32_t reduce,
                         float slope, float coef_keep, float feat_keep, uint64_t seed,
@@ -683,7 +721,15 @@ static int gat_fwd_impl(const char *name, int64_t n_dst, int32_t H, int32_t dp,
     GATMI_REQUIRE(n_dst >= 0 && n_items >= 0 && n_split >= 0, GATMI_EINVAL, "%s: negative size", name);
     if (n_dst == 0 || n_items == 0) return GATMI_OK;
     GATMI_REQUIRE(items && feat && f1 && out, GATMI_EINVAL, "%s: null pointer", name);
-    GATMI_REQUIRE((f2 != nullptr) != (logit_a2 != nullptr), GATMI_EINVAL, "%s: give either the table f2 or logit_a2 (f2 formed from the gathered rows), not both or neither", name);
+    GATMI_REQUIRE(feat_dtype == GATMI_DTYPE_F32 || feat_dtype == GATMI_DTYPE_BF16, GATMI_EUNSUPPORTED, "%s: feat_dtype %d", name, feat_dtype);
+    if (feat_dtype == GATMI_DTYPE_F32) {
+        GATMI_REQUIRE((f2 != nullptr) != (logit_a2 != nullptr), GATMI_EINVAL, "%s: give either the table f2 or logit_a2 (f2 formed from the gathered rows), not both or neither", name);
+        GATMI_REQUIRE(ldfeat >= (int64_t)H * dp && ldfeat % 4 == 0, GATMI_EINVAL, "%s: row stride ldfeat=%lld (>= hd, a multiple of 4)", name, (long long)ldfeat);
+    } else {
+        GATMI_REQUIRE(!logit_a2, GATMI_EINVAL, "%s: bf16 rows take f2 from the table or from their records (f2 = NULL), not from logit_a2", name);
+        GATMI_REQUIRE(ldfeat >= (int64_t)H * dp + (f2 ? 0 : 2 * H) && ldfeat % 4 == 0, GATMI_EINVAL,
+                      "%s: row stride ldfeat=%lld (bf16 elements; >= hd, or >= hd + 2H for records that carry f2; a multiple of 4)", name, (long long)ldfeat);
+    }
     GATMI_REQUIRE(logit_a2 || !logit_b2, GATMI_EINVAL, "%s: logit_b2 goes with logit_a2", name);
     GATMI_REQUIRE_ALIGNED(logit_a2);
     GATMI_REQUIRE(n_split == 0 || (split && ws), GATMI_EINVAL, "%s: split rows need `split` and a partial-result store", name);
@@ -698,12 +744,11 @@ static int gat_fwd_impl(const char *name, int64_t n_dst, int32_t H, int32_t dp,
     FwdArgs a;
     a.items = reinterpret_cast<const int4 *>(items);
     a.n_items = n_items;
-    a.col = col; a.feat = feat; a.f1 = f1; a.f2 = f2; a.la2 = logit_a2; a.lb2 = logit_b2; a.bias = bias; a.resid = resid;
+    a.col = col; a.feat = feat; a.ldf = ldfeat; a.f1 = f1; a.f2 = f2; a.la2 = logit_a2; a.lb2 = logit_b2; a.bias = bias; a.resid = resid;
     a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.ws = ws; a.ws_slots = ws_slots;
     a.activation = activation; a.reduce = reduce;
     a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
     const bool drop = coef_keep < 1.f || feat_keep < 1.f;
-    GATMI_REQUIRE(feat_dtype == GATMI_DTYPE_F32 || feat_dtype == GATMI_DTYPE_BF16, GATMI_EUNSUPPORTED, "%s: feat_dtype %d", name, feat_dtype);
     const bool bf16 = feat_dtype == GATMI_DTYPE_BF16;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int4 *sp = reinterpret_cast<const int4 *>(split);
@@ -715,14 +760,14 @@ static int gat_fwd_impl(const char *name, int64_t n_dst, int32_t H, int32_t dp,
 
 extern "C" int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
                              const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
-                             const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
+                             const int32_t *col, const void *feat, int32_t feat_dtype, int64_t ldfeat, const float *f1, const float *f2,
                              const float *logit_a2, const float *logit_b2,
                              const float *bias, const float *resid, int32_t activation, int32_t reduce,
                              float slope, float coef_keep, float feat_keep, uint64_t seed,
                              float *out, float *agg, float *pos, float *lse, float *q,
                              float *ws, void *stream) {
     // the caller sized `ws` with gatmi_gat_fwd_ws_floats for its own slot count: no limit to enforce here
-    return gat_fwd_impl("gat_fwd", n_dst, H, dp, items, n_items, split, n_split, col, feat, feat_dtype, f1, f2, logit_a2, logit_b2, bias, resid,
+    return gat_fwd_impl("gat_fwd", n_dst, H, dp, items, n_items, split, n_split, col, feat, feat_dtype, ldfeat, f1, f2, logit_a2, logit_b2, bias, resid,
                         activation, reduce, slope, coef_keep, feat_keep, seed, out, agg, pos, lse, q, ws, INT64_MAX, stream);
 }
 
@@ -753,7 +798,7 @@ int scratch_for_current_device(float **out) {
 extern "C" int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
                                      const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                                      int64_t n_slots,
-                                     const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
+                                     const int32_t *col, const void *feat, int32_t feat_dtype, int64_t ldfeat, const float *f1, const float *f2,
                                      const float *logit_a2, const float *logit_b2,
                                      const float *bias, const float *resid, int32_t activation, int32_t reduce,
                                      float slope, float coef_keep, float feat_keep, uint64_t seed,
@@ -771,7 +816,7 @@ extern "C" int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
     }
     // Nothing in the store has to start at zero: each piece's record is written whole by the row kernel
     // before the merge kernel, ordered behind it on `stream`, reads it.
-    return gat_fwd_impl("gat_fwd_noalloc", n_dst, H, dp, items, n_items, split, n_split, col, feat, feat_dtype, f1, f2, logit_a2, logit_b2, bias, resid,
+    return gat_fwd_impl("gat_fwd_noalloc", n_dst, H, dp, items, n_items, split, n_split, col, feat, feat_dtype, ldfeat, f1, f2, logit_a2, logit_b2, bias, resid,
                         activation, reduce, slope, coef_keep, feat_keep, seed, out, agg, pos, lse, q, ws, n_slots, stream);
 }
 
@@ -781,8 +826,8 @@ extern "C" int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
                                   const float *dout, const float *out, const float *agg, const float *pos,
                                   const float *q, const float *f1, const float *lse, const float *bias,
                                   int32_t activation, int32_t reduce, float slope,
-                                  float *g, int64_t ldg, uint16_t *g16, float *stats, int64_t lds, float *df1, float *dbias, float *ws,
-                                  void *stream) {
+                                  float *g, int64_t ldg, uint16_t *g16, int64_t ldg16, float *stats, int64_t lds, float *df1, float *dbias,
+                                  float *ws, void *stream) {
     int G, LPH;
     int rc = check_shape(H, dp, &G, &LPH);
     if (rc) return rc;
@@ -798,7 +843,8 @@ extern "C" int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
     a.n = n_dst; a.dout = dout; a.out = out; a.bias = out ? nullptr : bias; a.agg = agg; a.pos = pos; a.q = q; a.f1 = f1; a.lse = lse;
     GATMI_REQUIRE((!g || (ldg >= (int64_t)H * dp && ldg % 4 == 0)) && lds >= 3 * (int64_t)H, GATMI_EINVAL,
                   "gat_bwd_node: row strides ldg=%lld (>= hd, multiple of 4) lds=%lld (>= 3H)", (long long)ldg, (long long)lds);
-    a.g = g; a.ldg = ldg; a.g16 = reinterpret_cast<uint32_t *>(g16); a.stats = stats; a.lds = lds; a.df1 = df1; a.ws = ws;
+    GATMI_REQUIRE(!g16 || (ldg16 >= (int64_t)H * dp && ldg16 % 4 == 0), GATMI_EINVAL, "gat_bwd_node: row stride ldg16=%lld (>= hd, multiple of 4)", (long long)ldg16);
+    a.g = g; a.ldg = ldg; a.g16 = reinterpret_cast<uint32_t *>(g16); a.ldg16 = ldg16; a.stats = stats; a.lds = lds; a.df1 = df1; a.ws = ws;
     a.activation = activation; a.reduce = reduce; a.slope = slope;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X(gg, l) if (G == gg && LPH == l) return launch_bwd_node<gg, l>(a, dbias, st);
@@ -828,6 +874,7 @@ extern "C" int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
     GATMI_REQUIRE(items && g && stats && feat && dfeat && df2, GATMI_EINVAL, "gat_bwd_csc: null pointer");
     GATMI_REQUIRE((f2 != nullptr) != (logit_a2 != nullptr), GATMI_EINVAL, "gat_bwd_csc: give either the table f2 or logit_a2 (f2 formed from the rows of feat), as the forward call did");
     GATMI_REQUIRE(logit_a2 || !logit_b2, GATMI_EINVAL, "gat_bwd_csc: logit_b2 goes with logit_a2");
+    GATMI_REQUIRE(g_dtype != GATMI_DTYPE_BF16 || f2, GATMI_EINVAL, "gat_bwd_csc: with bf16 rows the source logit half comes from the table f2 (the forward pass read the same fp32 values)");
     GATMI_REQUIRE_ALIGNED(logit_a2);
     GATMI_REQUIRE((a1 == nullptr) == (a2 == nullptr) && (!a1 || df1), GATMI_EINVAL, "gat_bwd_csc: a1, a2 and df1 go together");
     GATMI_REQUIRE(n_split == 0 || (split && ws), GATMI_EINVAL, "gat_bwd_csc: split rows need `split` and `ws`");

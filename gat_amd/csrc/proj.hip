@@ -33,7 +33,8 @@ struct GemmArgs {
     int Nc;
     float *C;         // [n, Nc], row stride ldc
     int64_t ldc;
-    uint32_t *C16;    // optional second copy of C in bf16, [n, Nc] contiguous (Nc % 4 == 0), two values per dword
+    uint32_t *C16;    // optional second copy of C in bf16 (Nc % 4 == 0), two values per dword, rows ldc16 dwords apart;
+    int64_t ldc16;    //   with the fused logit halves, f2 of the row follows its Nc bf16 values (fp32, dword Nc/2 + head)
     int accumulate;
     const float *cbias;  // [Nc] added to C, or null
     // fused logit halves (only when the whole row is inside one column tile)
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
             if (row < g.n && col < g.Nc && (c4 % g.LPH) == 0) {
                 g.f1[row * g.H + head] = p1 + g.b1[head];
                 g.f2[row * g.H + head] = p2 + g.b2[head];
+                if (g.C16) reinterpret_cast<float *>(g.C16)[row * g.ldc16 + g.Nc / 2 + head] = p2 + g.b2[head];
             }
         }
         if (row >= g.n || col >= g.Nc) continue;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             }
             *reinterpret_cast<float4 *>(cp) = v;
-            if (g.C16) *reinterpret_cast<uint2 *>(g.C16 + (row * g.Nc + col) / 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+            if (g.C16) *reinterpret_cast<uint2 *>(g.C16 + row * g.ldc16 + col / 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
         } else {
             const float vv[4] = {v.x, v.y, v.z, v.w};
             for (int t = 0; t < 4 && col + t < g.Nc; ++t) cp[t] = g.accumulate ? cp[t] + vv[t] : vv[t];
@@ -331,12 +333,13 @@ __global__ __launch_bounds__(64 * kResWaves) void proj_resident_kernel(GemmArgs 
                 if (row < g.n && col < g.Nc && (c4 % g.LPH) == 0) {
                     g.f1[row * g.H + head] = p1 + g.b1[head];
                     g.f2[row * g.H + head] = p2 + g.b2[head];
+                    if (g.C16) reinterpret_cast<float *>(g.C16)[row * g.ldc16 + g.Nc / 2 + head] = p2 + g.b2[head];
                 }
             }
             if (row < g.n && col < g.Nc) {
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 store_stream4(g.C + row * g.ldc + col, v);
-                if (g.C16) *reinterpret_cast<uint2 *>(g.C16 + (row * g.Nc + col) / 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                if (g.C16) *reinterpret_cast<uint2 *>(g.C16 + row * g.ldc16 + col / 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(64 * kResWaves) void proj_resident_kernel(GemmArgs 
 template <int G>
 __global__ __launch_bounds__(256) void logit_halves_kernel(const float *Wh, int64_t n, int H, int LPH,
                                                             const float *a1, const float *a2, const float *b1,
-                                                            const float *b2, float *f1, float *f2) {
+                                                            const float *b2, float *f1, float *f2, float *rec, int64_t ldrec) {
     constexpr int RPW = 64 / G;
     constexpr int HD = 4 * G;
     const int lane = threadIdx.x & 63;
@@ -371,6 +374,7 @@ __global__ __launch_bounds__(256) void logit_halves_kernel(const float *Wh, int6
         if (sub % LPH == 0) {
             f1[row * H + head] = p1 + b1[head];
             f2[row * H + head] = p2 + b2[head];
+            if (rec) rec[row * ldrec + HD / 2 + head] = p2 + b2[head];     // bf16 record of the row: f2 behind its HD bf16 values
         }
     }
 }
@@ -697,10 +701,10 @@ static int launch_tall_gemm(const GemmArgs &g, hipStream_t st, const char *name)
 
 template <int G>
 static int launch_logit_halves(const float *Wh, int64_t n, int H, int LPH, const float *a1, const float *a2,
-                               const float *b1, const float *b2, float *f1, float *f2, hipStream_t st) {
+                               const float *b1, const float *b2, float *f1, float *f2, float *rec, int64_t ldrec, hipStream_t st) {
     const int64_t per_block = 4 * (64 / G);
     const unsigned nb = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(1, (n + per_block - 1) / per_block));
-    hipLaunchKernelGGL(logit_halves_kernel<G>, dim3(nb), dim3(256), 0, st, Wh, n, H, LPH, a1, a2, b1, b2, f1, f2);
+    hipLaunchKernelGGL(logit_halves_kernel<G>, dim3(nb), dim3(256), 0, st, Wh, n, H, LPH, a1, a2, b1, b2, f1, f2, rec, ldrec);
     GATMI_LAUNCH_CHECK("logit_halves");
     return GATMI_OK;
 }
@@ -828,7 +832,7 @@ extern "C" int gatmi_proj_bwd_params_csr(const int64_t *xt_rowptr, const int32_t
 extern "C" int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t ldx,
                               const float *W, const float *a1, const float *a2,
                               const float *b1, const float *b2, int32_t H, int32_t dp,
-                              float *Wh, uint16_t *Wh16, float *f1, float *f2,
+                              float *Wh, uint16_t *Wh16, int64_t ld16, float *f1, float *f2,
                               const float *W_res, const float *b_res, float *res_out, void *stream) {
     int G, LPH;
     int rc = check_shape(H, dp, &G, &LPH);
@@ -843,7 +847,10 @@ extern "C" int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t l
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int hd = H * dp;
     GemmArgs g{};
+    GATMI_REQUIRE(!Wh16 || (logits && ld16 >= (int64_t)hd + 2 * H && ld16 % 8 == 0), GATMI_EINVAL,
+                  "proj_fwd: Wh16 records need the logit halves and a row stride ld16=%lld >= hd + 2H, a multiple of 8", (long long)ld16);
     g.C16 = reinterpret_cast<uint32_t *>(Wh16);
+    g.ldc16 = ld16 / 2;
     g.A = X; g.n = n; g.K = f_in; g.lda = ldx;
     g.B = W; g.sbk = hd; g.sbc = 1; g.Nc = hd;
     g.C = Wh; g.ldc = hd; g.accumulate = 0; g.cbias = nullptr;
@@ -852,8 +859,9 @@ extern "C" int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t l
     rc = launch_tall_gemm(g, st, "proj_fwd");
     if (rc) return rc;
     if (logits && !fused) {
-        if (G == 32) rc = launch_logit_halves<32>(Wh, n, H, LPH, a1, a2, b1, b2, f1, f2, st);
-        else rc = launch_logit_halves<64>(Wh, n, H, LPH, a1, a2, b1, b2, f1, f2, st);
+        float *rec = reinterpret_cast<float *>(Wh16);
+        if (G == 32) rc = launch_logit_halves<32>(Wh, n, H, LPH, a1, a2, b1, b2, f1, f2, rec, ld16 / 2, st);
+        else rc = launch_logit_halves<64>(Wh, n, H, LPH, a1, a2, b1, b2, f1, f2, rec, ld16 / 2, st);
         if (rc) return rc;
     }
     if (W_res) {

@@ -375,19 +375,25 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         f1 = ops._new((n_proj, H), x)
         b2c = b2.reshape(H).contiguous()
         bf16 = cfg.storage == "bf16"
-        gtab, gdt = feat, _lib.DTYPE_F32
+        gtab, gdt, ldf = feat, _lib.DTYPE_F32, hd
         if bf16:
-            # bf16 mode: the gathered table (a second store of the projection's epilogue) and therefore the halo
-            # rows on the wire are bf16 (half the forward exchange); the fp32 rows stay for the backward sweep and
-            # the parameter gradients
-            gtab, gdt = torch.empty((n_src, hd), dtype=torch.bfloat16, device=x.device), _lib.DTYPE_BF16
+            # bf16 mode: the gathered table (a second store of the projection's epilogue: one record
+            # [hd bf16 | the row's fp32 f2 | pad] per row) and therefore the halo rows on the wire are bf16
+            # (0.6 of the forward exchange); the fp32 rows stay for the backward sweep and the parameter gradients
+            ldf = ops._bf16_record_elems(H, dp)
+            gtab, gdt = torch.empty((n_src, ldf), dtype=torch.bfloat16, device=x.device), _lib.DTYPE_BF16
         _lib.call("gatmi_proj_fwd", ptr(x), n_proj, F, x.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1.contiguous()),
-                  ptr(b2c), H, dp, ptr(feat), ptr(gtab) if bf16 else None, ptr(f1), ptr(f2), None, None, None, st)
+                  ptr(b2c), H, dp, ptr(feat), ptr(gtab) if bf16 else None, ldf, ptr(f1), ptr(f2), None, None, None, st)
         ticket = None
         if not replicate:
             # fp32: only the Wh rows travel, the receiving sweep forms <Wh_j, a2> + b2 from them; bf16 rows
-            # would add their rounding to the logits, so there the fp32 f2 rows travel along
-            ticket = ex.gather_halo_pack([(gtab.view(torch.float32), hd // 2), (f2, H)] if bf16 else [(feat, hd)])
+            # would add their rounding to the logits, so their records carry the exact f2 along
+            ticket = ex.gather_halo_pack([(gtab.view(torch.float32), ldf // 2)] if bf16 else [(feat, hd)])
+
+        def widen_halo():
+            # the per-source backward sweep reads its own Wh row and f2 in fp32: exact widening of what arrived
+            feat[n:].copy_(gtab[n:, :hd])
+            f2[n:].copy_(gtab.view(torch.float32)[n:, hd // 2:hd // 2 + H])
         biasp = None if bias is None else ops._pad_last(bias.reshape(H, D), D, dp).reshape(hd)
         need_grad = any(ctx.needs_input_grad)
         out = ops._new((n, dp if cfg.reduce == "mean" else hd), x)
@@ -396,11 +402,11 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             agg, pos = ops._new((n, hd), x), ops._new((n, hd), x)
             lse, q = ops._new((n, H), x), ops._new((n, H), x)
 
-        half = (ptr(f2), None, None) if bf16 else (None, ptr(a2p), ptr(b2c))        # the source half of the logits
+        half = (None, None, None) if bf16 else (None, ptr(a2p), ptr(b2c))           # the source half of the logits comes with the rows
 
         def sweep(items, split, ws):
             _lib.call("gatmi_gat_fwd", n, H, dp, ptr(items), len(items), ptr(split) if len(split) else None, len(split),
-                      ptr(graph.col), ptr(gtab), gdt, ptr(f1), *half, ptr(biasp), None,
+                      ptr(graph.col), ptr(gtab), gdt, ldf, ptr(f1), *half, ptr(biasp), None,
                       ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
                       ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
         two_phase = ticket is not None and overlap and len(pgraph.items_a) and len(pgraph.items_b)
@@ -409,13 +415,13 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             sweep(pgraph.items_a, pgraph.split_ab[:0], ws)       # entries reading owned rows, beside the exchange
             ex.gather_halo_start(ticket).wait()
             if bf16:
-                feat[n:].copy_(gtab[n:])        # the per-source backward sweep reads its own Wh row in fp32 (exact widening)
+                widen_halo()
             sweep(pgraph.items_b, pgraph.split_ab, ws)           # entries reading halo rows; merges rows cut further
         else:
             if ticket is not None:
                 ex.gather_halo_start(ticket).wait()
                 if bf16:
-                    feat[n:].copy_(gtab[n:])
+                    widen_halo()
             ws = None
             if len(graph.split_csr):
                 ws = ops._new((_lib.lib.gatmi_gat_fwd_ws_floats(graph.n_slots_csr, H, dp),), x)
@@ -442,13 +448,16 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         else:
             dout = ops._pad_last(dout.reshape(n, H, D), D, dp).reshape(n, hd)
         bf16 = cfg.storage == "bf16"
-        g16 = torch.empty((n, hd), dtype=torch.bfloat16, device=x.device) if bf16 else None
+        g = g16 = None
         if bf16:
-            g, stats = None, ops._new((n, 3 * H), x)
+            ldg = ops._bf16_grad_record_elems(H, dp)             # [g: hd bf16 | f1 lse c | pad] per row
+            g16 = torch.empty((n, ldg), dtype=torch.bfloat16, device=x.device)
+            stats = g16.view(torch.float32)[:, hd // 2:hd // 2 + 3 * H]
         else:
             rec = ops._new((n, ops._record_width(H, dp)), x)    # [g | f1 lse c | pad] per row: one gather per entry
             g, stats = rec[:, :hd], rec[:, hd:hd + 3 * H]
-        ldg, lds = (hd if bf16 else g.stride(0)), stats.stride(0)
+            ldg = rec.stride(0)
+        lds = stats.stride(0)
         if replicate:
             # halo rows are no destinations here: their logit gradient df1 belongs to their owner
             df1 = torch.zeros((n_src, H), dtype=torch.float32, device=x.device)
@@ -457,7 +466,7 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         dbias = ops._new((hd,), x)
         ws = ops._new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x)
         _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), None, ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse), ptr(biasp),
-                  ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, ptr(g), ldg, ptr(g16), ptr(stats), lds, ptr(df1), ptr(dbias), ptr(ws), st)
+                  ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, ptr(g), ldg, ptr(g16), ldg, ptr(stats), lds, ptr(df1), ptr(dbias), ptr(ws), st)
         dfeat = ops._new((n_src, hd), x)
         df2 = ops._new((n_src, H), x)
         ws2 = None

@@ -53,6 +53,16 @@ class _Cfg:
     __slots__ = ("H", "D", "dp", "activation", "reduce", "slope", "coef_keep", "feat_keep", "seed", "storage", "mask_path")
 
 
+def _bf16_record_elems(H, dp):
+    """bf16 elements per row of the forward gather records [hd bf16 | f2: H fp32 | pad]: whole 64-byte pieces."""
+    return (2 * H * dp + 4 * H + 63) // 64 * 32
+
+
+def _bf16_grad_record_elems(H, dp):
+    """bf16 elements per row of the backward records [g: hd bf16 | f1 lse c: 3H fp32 | pad]: whole 128-byte lines."""
+    return (2 * H * dp + 12 * H + 127) // 128 * 64
+
+
 def _record_width(H, dp):
     """Floats per row of the [g | f1 lse c | pad] records the backward kernels exchange: whole 128-byte lines."""
     return (H * dp + 3 * H + 31) // 32 * 32
@@ -64,10 +74,8 @@ def _new(shape, like, dtype=torch.float32):
 
 def _project(x2d, W, a1, a2, b1, b2, cfg, W_res=None, b_res=None, Wh16_out=None):
     """K1: Wh = X.W (+ f1, f2) on [n, F] rows (dense tensor or SparseFeatures).  Returns padded
-    parameter views and outputs.  Wh16_out: a list that receives an [n, hd] bfloat16 copy of Wh written by
-    the projection's epilogue (dense X only).  It is allocated here, after the fp32 outputs: the forward
-    kernel gathers from it and from the f2 table, and with the allocations the other way round it measured
-    15 % slower at the benchmark size."""
+    parameter views and outputs.  Wh16_out: a list that receives the bf16 gather table of the forward kernel,
+    one record [hd bf16 of Wh | the row's fp32 f2 | pad] per row, written by the projection's epilogue."""
     n, F = x2d.shape
     sparse_x = isinstance(x2d, SparseFeatures)
     if sparse_x and W_res is not None:
@@ -87,16 +95,19 @@ def _project(x2d, W, a1, a2, b1, b2, cfg, W_res=None, b_res=None, Wh16_out=None)
         Wrp = _pad_last(W_res.reshape(F, H, D), D, dp).reshape(F, hd)
         brp = _pad_last(b_res.reshape(H, D), D, dp).reshape(hd)
         res = _new((n, hd), x2d)
-    Wh16 = None
-    if Wh16_out is not None and not sparse_x:
-        Wh16 = torch.empty((n, hd), dtype=torch.bfloat16, device=Wh.device)
+    Wh16, ld16 = None, 0
+    if Wh16_out is not None:
+        ld16 = _bf16_record_elems(H, dp)
+        Wh16 = torch.empty((n, ld16), dtype=torch.bfloat16, device=Wh.device)
         Wh16_out.append(Wh16)
     if sparse_x:
         _lib.call("gatmi_proj_fwd_csr", ptr(x2d.rowptr), ptr(x2d.col), ptr(x2d.val), n, F, ptr(Wp), ptr(a1p), ptr(a2p),
                   ptr(b1c), ptr(b2c), H, dp, ptr(Wh), ptr(f1), ptr(f2), _lib.current_stream())
+        if Wh16 is not None:
+            _lib.call("gatmi_to_bf16_records", ptr(Wh), ptr(f2), n, H, dp, ld16, ptr(Wh16), _lib.current_stream())
         return Wp, a1p, a2p, None, Wh, f1, f2, None
     _lib.call("gatmi_proj_fwd", ptr(x2d), n, F, x2d.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1c), ptr(b2c),
-              H, dp, ptr(Wh), ptr(Wh16), ptr(f1), ptr(f2), ptr(Wrp), ptr(brp), ptr(res), _lib.current_stream())
+              H, dp, ptr(Wh), ptr(Wh16), ld16, ptr(f1), ptr(f2), ptr(Wrp), ptr(brp), ptr(res), _lib.current_stream())
     return Wp, a1p, a2p, Wrp, Wh, f1, f2, res
 
 
@@ -152,9 +163,11 @@ class SparseGATLayerFn(torch.autograd.Function):
         made16 = [] if cfg.storage == "bf16" else None
         Wp, a1p, a2p, Wrp, Wh, f1, f2, res = _project(x, W, a1, a2, b1, b2, cfg, W_res, b_res, made16)
         # fp32 rows: the kernels form the source half of the logits, <Wh_j, a2> + b2, from the rows they gather
-        # (b2c given, no f2 table); bf16 rows would add their rounding to the logits, so that mode gathers the table
-        b2c = _f32(b2).reshape(H).contiguous() if cfg.storage != "bf16" else None
-        if b2c is not None:
+        # (b2c given, no f2 gather); bf16 rows would add their rounding to the logits, so their records carry
+        # the exact f2 behind the row (no f2 gather either; the per-source backward kernel reads the f2 table)
+        bf16 = cfg.storage == "bf16"
+        b2c = None if bf16 else _f32(b2).reshape(H).contiguous()
+        if not bf16:
             f2 = None
         biasp = None if bias is None else _pad_last(bias.reshape(H, D), D, dp).reshape(hd)
         need_grad = any(ctx.needs_input_grad)
@@ -167,17 +180,12 @@ class SparseGATLayerFn(torch.autograd.Function):
         ws = None
         if len(graph.split_csr):
             ws = _new((_lib.lib.gatmi_gat_fwd_ws_floats(graph.n_slots_csr, H, dp),), x)
-        feat, fdt = Wh, _lib.DTYPE_F32
-        if cfg.storage == "bf16":
-            if made16:
-                feat = made16[0]                             # written by the projection's epilogue
-            else:
-                feat = torch.empty((n, hd), dtype=torch.bfloat16, device=Wh.device)
-                _lib.call("gatmi_to_bf16", ptr(Wh), n * hd, ptr(feat), st)
-            fdt = _lib.DTYPE_BF16
+        feat, fdt, ldf = Wh, _lib.DTYPE_F32, hd
+        if bf16:
+            feat, fdt, ldf = made16[0], _lib.DTYPE_BF16, made16[0].shape[1]
         _lib.call("gatmi_gat_fwd", n, H, dp, ptr(graph.items_csr), len(graph.items_csr),
                   ptr(graph.split_csr) if len(graph.split_csr) else None, len(graph.split_csr),
-                  ptr(graph.col), ptr(feat), fdt, ptr(f1), ptr(f2), ptr(a2p) if f2 is None else None, ptr(b2c), ptr(biasp), ptr(res),
+                  ptr(graph.col), ptr(feat), fdt, ldf, ptr(f1), None, None if bf16 else ptr(a2p), ptr(b2c), ptr(biasp), ptr(res),
                   _ACT[cfg.activation], _RED[cfg.reduce], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
                   ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
         if need_grad:
@@ -204,22 +212,29 @@ class SparseGATLayerFn(torch.autograd.Function):
         else:
             dout = _pad_last(dout.reshape(n, H, D), D, dp).reshape(n, hd)
         bf16 = cfg.storage == "bf16"
-        g16 = torch.empty((n, hd), dtype=torch.bfloat16, device=x.device) if bf16 else None
-        if bf16 or ctx.has_res:
-            g = _new((n, hd), x) if ctx.has_res else None                # the residual branch reads contiguous fp32 g
-            stats = _new((n, 3 * H), x)
+        # one record per destination row, [g | f1 lse c | pad]: the per-source kernel's two gathers per entry
+        # read one contiguous piece of memory (g in bf16 with storage="bf16")
+        g = g16 = None
+        ldg = ldg16 = hd
+        if bf16:
+            ldg16 = _bf16_grad_record_elems(H, dp)
+            g16 = torch.empty((n, ldg16), dtype=torch.bfloat16, device=x.device)
+            stats = g16.view(torch.float32)[:, hd // 2:hd // 2 + 3 * H]
+            if ctx.has_res:
+                g = _new((n, hd), x)                                      # the residual branch reads contiguous fp32 g
+        elif ctx.has_res:
+            g, stats = _new((n, hd), x), _new((n, 3 * H), x)
         else:
-            # one record per destination row, [g | f1 lse c]: the per-source kernel's two gathers per entry
-            # read one contiguous piece of memory
             rec = _new((n, _record_width(H, dp)), x)
             g, stats = rec[:, :hd], rec[:, hd:hd + 3 * H]
-        ldg, lds = (g.stride(0) if g is not None else hd), stats.stride(0)
+            ldg = rec.stride(0)
+        lds = stats.stride(0)
         df1 = _new((n, H), x)
         dbias = _new((hd,), x)
         ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x)
         # without a residual the pre-activation is agg + bias: the kernel then does not read `out`
         _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out) if ctx.has_res else None, ptr(agg), ptr(pos), ptr(q), ptr(f1),
-                  ptr(lse), ptr(biasp), _ACT[cfg.activation], _RED[cfg.reduce], cfg.slope, ptr(g), ldg, ptr(g16), ptr(stats), lds, ptr(df1),
+                  ptr(lse), ptr(biasp), _ACT[cfg.activation], _RED[cfg.reduce], cfg.slope, ptr(g), ldg, ptr(g16), ldg16, ptr(stats), lds, ptr(df1),
                   ptr(dbias), ptr(ws), st)
         gtab, gdt = (g16, _lib.DTYPE_BF16) if bf16 else (g, _lib.DTYPE_F32)
         dWh = _new((n, hd), x)
@@ -229,7 +244,7 @@ class SparseGATLayerFn(torch.autograd.Function):
             ws2 = _new((_lib.lib.gatmi_gat_bwd_ws_floats(graph.n_slots_csc, H, dp),), x)
         _lib.call("gatmi_gat_bwd_csc", n, H, dp, ptr(graph.items_csc), len(graph.items_csc),
                   ptr(graph.split_csc) if len(graph.split_csc) else None, len(graph.split_csc),
-                  ptr(graph.rowidx), ptr(graph.perm), ptr(gtab), gdt, hd if bf16 else ldg, ptr(stats), lds, ptr(Wh), ptr(f2), ptr(a2p) if f2 is None else None, ptr(b2c),
+                  ptr(graph.rowidx), ptr(graph.perm), ptr(gtab), gdt, ldg16 if bf16 else ldg, ptr(stats), lds, ptr(Wh), ptr(f2), None if bf16 else ptr(a2p), ptr(b2c),
                   ptr(df1), ptr(a1p), ptr(a2p), cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(dWh), ptr(df2), ptr(ws2), st)
         dx, dW, da1, da2, db1, db2, dWr = _project_backward(x, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
         db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None
@@ -361,7 +376,7 @@ class DenseGATLayerFn(torch.autograd.Function):
         dbias = _new((hd,), x2)
         ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x2)
         _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out) if ctx.has_res else None, ptr(agg), ptr(pos), ptr(q), ptr(f1),
-                  ptr(lse), ptr(biasp), _ACT[cfg.activation], _lib.REDUCE_CONCAT, cfg.slope, ptr(g), hd, None, ptr(stats), 3 * H, ptr(df1),
+                  ptr(lse), ptr(biasp), _ACT[cfg.activation], _lib.REDUCE_CONCAT, cfg.slope, ptr(g), hd, None, 0, ptr(stats), 3 * H, ptr(df1),
                   ptr(dbias), ptr(ws), st)
         dWh = _new((n, hd), x2)
         df2 = _new((n, H), x2)
@@ -468,7 +483,7 @@ class BnfAggregateFn(torch.autograd.Function):
         df1 = _new((n, H), xp)
         ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, fp),), xp)
         _lib.call("gatmi_gat_bwd_node", n, H, fp, ptr(G), None, ptr(t2n), ptr(t2pos), ptr(q), ptr(f1), ptr(lse), None,
-                  _lib.ACT_IDENTITY, _lib.REDUCE_CONCAT, slope, ptr(g), H * fp, None, ptr(stats), 3 * H, ptr(df1), None, ptr(ws), st)
+                  _lib.ACT_IDENTITY, _lib.REDUCE_CONCAT, slope, ptr(g), H * fp, None, 0, ptr(stats), 3 * H, ptr(df1), None, ptr(ws), st)
         dx = _new((n, fp), xp)
         dA = _new((B, N, N), xp)
         df2 = _new((n, H), xp)

@@ -130,14 +130,15 @@ int gatmi_halo_plan(int32_t nparts, int32_t rank, const int64_t *part, int64_t n
 /* Feature projection with the logit halves fused: replaces utils/layers.py:11 (seq_fts = X.W,
  * no bias), :14 (f_1 = seq_fts.a1 + b1) and :15 (f_2 = seq_fts.a2 + b2) for all H heads at once.
  *   X [n, f_in] (row stride ldx floats), W [f_in, hd], a1,a2 [hd], b1,b2 [H]
- *   Wh [n, hd], f1,f2 [n, H].  Wh16 [n, hd]: optional second copy of Wh in bf16 (round to nearest even,
- *   written from the same registers), the gather-side table of GATMI_DTYPE_BF16; NULL to skip.
+ *   Wh [n, hd], f1,f2 [n, H].  Wh16: optional bf16 gather table for GATMI_DTYPE_BF16 (NULL to skip), written
+ *   from the same registers: one record per row, ld16 bf16 elements apart (ld16 >= hd + 2H, a multiple of 8),
+ *   [hd bf16 values of Wh, round to nearest even | the row's H fp32 f2 values | padding, left untouched].
  *   W_res/b_res/res_out: optional second projection of the same X (residual branch, utils/layers.py:30),
  *   NULL to skip. */
 int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t ldx,
                    const float *W, const float *a1, const float *a2,
                    const float *b1, const float *b2, int32_t H, int32_t dp,
-                   float *Wh, uint16_t *Wh16, float *f1, float *f2,
+                   float *Wh, uint16_t *Wh16, int64_t ld16, float *f1, float *f2,
                    const float *W_res, const float *b_res, float *res_out, void *stream);
 
 /* Parameter gradients of the projection: dW = X^T . dWh [f_in, hd]; and, when Wh != NULL,
@@ -185,14 +186,16 @@ int gatmi_proj_bwd_params_csr(const int64_t *xt_rowptr, const int32_t *xt_row, c
  *   items/n_items, split/n_split : gatmi_work_items of the CSR rowptr (or a sub-list of them: only
  *       the rows named by the items are computed and written; the merge step runs for the rows in
  *       `split`; see gatmi_work_items_phased for the item encoding); col: CSR source ids
- *   feat [n_src, hd] gathered rows (Wh) stored as feat_dtype (GATMI_DTYPE_F32, or GATMI_DTYPE_BF16
- *       written by gatmi_to_bf16: dropout must then be off); f1 [n_dst, H]
- *   the source half of the logits (layers.py:15), one of two forms:
+ *   feat [n_src, hd] gathered rows (Wh), row stride ldfeat elements, stored as feat_dtype: GATMI_DTYPE_F32,
+ *       or GATMI_DTYPE_BF16 (the records gatmi_proj_fwd / gatmi_to_bf16_records write); f1 [n_dst, H]
+ *   the source half of the logits (layers.py:15), one of three forms:
  *       f2 [n_src, H], a table the kernel gathers from (logit_a2 = logit_b2 = NULL), or
- *       f2 = NULL and logit_a2 [hd] (+ logit_b2 [H], NULL = zeros): the kernel forms
+ *       fp32 rows, f2 = NULL and logit_a2 [hd] (+ logit_b2 [H], NULL = zeros): the kernel forms
  *       f2_j = <feat_j, logit_a2> + logit_b2 per head from the row it gathers anyway, which saves one
- *       request and 4H bytes per entry.  gatmi_gat_bwd_csc must be called in the same form, so that both
- *       passes see bit-identical logits (with GATMI_DTYPE_BF16 rows f2 is formed from the rounded rows).
+ *       scattered request per entry; gatmi_gat_bwd_csc must be called in the same form, so that both
+ *       passes see bit-identical logits; or
+ *       bf16 rows, f2 = NULL and logit_a2 = NULL: the exact fp32 f2 values of row j follow its hd bf16
+ *       values inside the record (ldfeat >= hd + 2H); gatmi_gat_bwd_csc then takes the f2 table.
  *   bias [hd] or NULL; resid [n_dst, hd] or NULL (per head, added before the activation; with
  *       GATMI_REDUCE_MEAN it is averaged over the heads together with the aggregate and the bias)
  *   out [n_dst, hd] (concat) or [n_dst, dp] (mean)
@@ -205,7 +208,7 @@ int gatmi_proj_bwd_params_csr(const int64_t *xt_rowptr, const int32_t *xt_row, c
 size_t gatmi_gat_fwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp);
 int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
                   const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
-                  const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
+                  const int32_t *col, const void *feat, int32_t feat_dtype, int64_t ldfeat, const float *f1, const float *f2,
                   const float *logit_a2, const float *logit_b2,
                   const float *bias, const float *resid, int32_t activation, int32_t reduce,
                   float slope, float coef_keep, float feat_keep, uint64_t seed,
@@ -228,7 +231,7 @@ int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
 int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
                           const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,
                           int64_t n_slots,
-                          const int32_t *col, const void *feat, int32_t feat_dtype, const float *f1, const float *f2,
+                          const int32_t *col, const void *feat, int32_t feat_dtype, int64_t ldfeat, const float *f1, const float *f2,
                           const float *logit_a2, const float *logit_b2,
                           const float *bias, const float *resid, int32_t activation, int32_t reduce,
                           float slope, float coef_keep, float feat_keep, uint64_t seed,
@@ -236,10 +239,13 @@ int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
 
 /* Backward, per-destination part (no gather).  From dOut and the saved forward tensors:
  *   g [n_dst, hd]    = dOut * activation'(out)              (dOut / H per head for mean), row stride ldg floats;
- *       g16: the same rows in bf16 (contiguous) for gatmi_gat_bwd_csc's gather; either of g / g16 may be NULL
+ *       g16: the same rows in bf16 (row stride ldg16 bf16 elements) for gatmi_gat_bwd_csc's gather; either of
+ *       g / g16 may be NULL
  *   stats [n_dst, 3, H] = {f1, lse, c}, c = <g, agg> per head, row stride lds floats.  g and stats may
- *       interleave in one buffer of [n_dst, hd + 3H] records (ldg = lds = hd + 3H, stats = g + hd): the two
- *       gathers per entry of gatmi_gat_bwd_csc then read one contiguous record
+ *       interleave in one buffer of records [g hd | f1 H | lse H | c H | pad] (stats = g + hd, ldg = lds >= hd + 3H;
+ *       bf16: stats right behind the hd bf16 values of g16, ldg16 = 2 lds): the two gathers per entry of
+ *       gatmi_gat_bwd_csc then read one contiguous record.  With H % 4 == 0 the kernel writes such records,
+ *       padding included (zeros), as whole 16-byte pieces: pad them to whole 128-byte lines.
  *   df1 [n_dst, H]   = (1 - slope) * (<g, pos> - c * q)     = sum_j dlogit_ij  (gradient of f_1)
  *   dbias [hd]       = sum_i g (NULL to skip);  dresid is g itself.
  *   activation': ELU / ReLU need the layer's pre-activation.  Pass `out` (the saved output; required
@@ -251,8 +257,8 @@ int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
                        const float *dout, const float *out, const float *agg, const float *pos,
                        const float *q, const float *f1, const float *lse, const float *bias,
                        int32_t activation, int32_t reduce, float slope,
-                       float *g, int64_t ldg, uint16_t *g16, float *stats, int64_t lds, float *df1, float *dbias, float *ws,
-                       void *stream);
+                       float *g, int64_t ldg, uint16_t *g16, int64_t ldg16, float *stats, int64_t lds, float *df1, float *dbias,
+                       float *ws, void *stream);
 
 /* Backward, per-source part: transposed SpMM + SDDMM over the CSC structure.
  *   items/split: gatmi_work_items of colptr; rowidx: CSC destination ids; perm: CSR position of
@@ -275,9 +281,14 @@ int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
                       float slope, float coef_keep, float feat_keep, uint64_t seed,
                       float *dfeat, float *df2, float *ws, void *stream);
 
-/* fp32 -> bf16 (round to nearest even) copy of a table, n_elems a multiple of 4: the gather-side
- * storage for GATMI_DTYPE_BF16. */
+/* fp32 -> bf16 (round to nearest even) copy of a table, n_elems a multiple of 4. */
 int gatmi_to_bf16(const float *src, int64_t n_elems, uint16_t *dst, void *stream);
+
+/* The bf16 gather records of gatmi_gat_fwd from finished fp32 rows (what gatmi_proj_fwd's Wh16 output writes
+ * from its epilogue): row r of dst = [src[r, 0..hd) as bf16 | f2[r, 0..H) as fp32 | padding, untouched],
+ * rows ld16 bf16 elements apart (ld16 >= hd + 2H, a multiple of 4). */
+int gatmi_to_bf16_records(const float *src, const float *f2, int64_t n, int32_t H, int32_t dp, int64_t ld16,
+                          uint16_t *dst, void *stream);
 
 /* Last step of the backward pass for owned rows when gatmi_gat_bwd_csc ran with a1 == NULL
  * (row-partitioned runs add the peers' halo contributions to dfeat / df2 first):

@@ -60,16 +60,16 @@ def test_gradient_checksums_and_determinism(big):
         out, agg, pos, lse, q = new(n, hd), new(n, hd), new(n, hd), new(n, H), new(n, H)
         ws = new(_lib.lib.gatmi_gat_fwd_ws_floats(g.n_slots_csr, H, D))
         _lib.call("gatmi_gat_fwd", n, H, D, ptr(g.items_csr), len(g.items_csr), ptr(g.split_csr), len(g.split_csr),
-                  ptr(g.col), ptr(Wh), _lib.DTYPE_F32, ptr(f1), ptr(f2), None, None, ptr(p["bias"].reshape(-1).contiguous()), None,
+                  ptr(g.col), ptr(Wh), _lib.DTYPE_F32, hd, ptr(f1), ptr(f2), None, None, ptr(p["bias"].reshape(-1).contiguous()), None,
                   _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, 1.0, 1.0, 0, ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
         gg, stats, df1, dbias = new(n, hd), new(n, 3 * H), new(n, H), new(hd)
         wsn = new(_lib.lib.gatmi_gat_bwd_node_ws_floats(H, D))
         _lib.call("gatmi_gat_bwd_node", n, H, D, ptr(dout), ptr(out), ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse), None,
-                  _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(gg), hd, None, ptr(stats), 3 * H, ptr(df1), ptr(dbias), ptr(wsn), st)
+                  _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(gg), hd, None, 0, ptr(stats), 3 * H, ptr(df1), ptr(dbias), ptr(wsn), st)
         # the same from the pre-activation agg + bias instead of the saved output (the form the layers use)
         gg2, stats2, df12, dbias2 = new(n, hd), new(n, 3 * H), new(n, H), new(hd)
         _lib.call("gatmi_gat_bwd_node", n, H, D, ptr(dout), None, ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse),
-                  ptr(p["bias"].reshape(-1).contiguous()), _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(gg2), hd, None, ptr(stats2),
+                  ptr(p["bias"].reshape(-1).contiguous()), _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(gg2), hd, None, 0, ptr(stats2),
                   3 * H, ptr(df12), ptr(dbias2), ptr(wsn), st)
         # (the saved-output form computes ELU' as out + 1, which loses relative accuracy where out is close to -1)
         assert torch.allclose(gg2, gg, rtol=1e-5, atol=2e-7 * float(gg.abs().max()))

@@ -39,7 +39,7 @@ def test_error_reporting():
     with pytest.raises(_lib.GatmiError):
         _lib.call("gatmi_csr_from_coo", n, 2, _lib.ptr(dst), _lib.ptr(src), 0, 0, 1, _lib.ptr(rowptr), _lib.ptr(col), None, ctypes.byref(out))
     # unsupported head shape is reported, not crashed on (no GPU is touched before validation)
-    rc = _lib.lib.gatmi_gat_fwd(1, 3, 8, None, 1, None, 0, None, None, 0, None, None, None, None, None, None, 0, 0, 0.2, 1.0, 1.0, 0,
+    rc = _lib.lib.gatmi_gat_fwd(1, 3, 8, None, 1, None, 0, None, None, 0, 24, None, None, None, None, None, None, 0, 0, 0.2, 1.0, 1.0, 0,
                                 None, None, None, None, None, None, None)
     assert rc == -3 and "power of two" in _lib.last_error()
 

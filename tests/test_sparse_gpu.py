@@ -215,12 +215,12 @@ def test_source_logit_half_formed_from_the_rows_matches_the_table(H, D):
         out, agg, pos, lse, q = new(n, hd), new(n, hd), new(n, hd), new(n, H), new(n, H)
         ws = new(max(1, _lib.lib.gatmi_gat_fwd_ws_floats(graph.n_slots_csr, H, dp)))
         _lib.call("gatmi_gat_fwd", n, H, dp, ptr(graph.items_csr), len(graph.items_csr), ptr(graph.split_csr), len(graph.split_csr),
-                  ptr(graph.col), ptr(Wh), _lib.DTYPE_F32, ptr(f1), *half, None, None, _lib.ACT_ELU, _lib.REDUCE_CONCAT,
+                  ptr(graph.col), ptr(Wh), _lib.DTYPE_F32, hd, ptr(f1), *half, None, None, _lib.ACT_ELU, _lib.REDUCE_CONCAT,
                   0.2, 1.0, 1.0, 0, ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
         g, stats, df1, dbias = new(n, hd), new(n, 3 * H), new(n, H), new(hd)
         wsn = new(_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp))
         _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), None, ptr(agg), ptr(pos), ptr(q), ptr(f1), ptr(lse), None,
-                  _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(g), hd, None, ptr(stats), 3 * H, ptr(df1), ptr(dbias), ptr(wsn), st)
+                  _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, ptr(g), hd, None, 0, ptr(stats), 3 * H, ptr(df1), ptr(dbias), ptr(wsn), st)
         dfeat, df2 = new(n, hd), new(n, H)
         wsb = new(max(1, _lib.lib.gatmi_gat_bwd_ws_floats(graph.n_slots_csc, H, dp)))
         _lib.call("gatmi_gat_bwd_csc", n, H, dp, ptr(graph.items_csc), len(graph.items_csc), ptr(graph.split_csc), len(graph.split_csc),
@@ -239,7 +239,7 @@ def test_source_logit_half_formed_from_the_rows_matches_the_table(H, D):
     for k in rows:
         assert torch.equal(rows[k], again[k])
     # giving both forms, or neither, is refused
-    rc = _lib.lib.gatmi_gat_fwd(n, H, dp, ptr(graph.items_csr), len(graph.items_csr), None, 0, ptr(graph.col), ptr(Wh), _lib.DTYPE_F32,
+    rc = _lib.lib.gatmi_gat_fwd(n, H, dp, ptr(graph.items_csr), len(graph.items_csr), None, 0, ptr(graph.col), ptr(Wh), _lib.DTYPE_F32, hd,
                                 ptr(f1), ptr(f2), ptr(a2p), None, None, None, _lib.ACT_ELU, _lib.REDUCE_CONCAT, 0.2, 1.0, 1.0, 0,
                                 ptr(new(n, hd)), None, None, None, None, None, st)
     assert rc == -1 and "either" in _lib.last_error()          # GATMI_EINVAL

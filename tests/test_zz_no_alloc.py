@@ -41,7 +41,7 @@ def _call(name, graph, cfg, Wh, f1, f2, bias, outs, ws=None, n_slots=None):
     head = [graph.n_dst, H, dp, ptr(graph.items_csr), len(graph.items_csr), sp, len(graph.split_csr)]
     if name == "gatmi_gat_fwd_noalloc":
         head.append(graph.n_slots_csr if n_slots is None else n_slots)
-    tail = [ptr(graph.col), ptr(Wh), _lib.DTYPE_F32, ptr(f1), ptr(f2), None, None, ptr(bias), None, _lib.ACT_ELU, _lib.REDUCE_CONCAT,
+    tail = [ptr(graph.col), ptr(Wh), _lib.DTYPE_F32, H * dp, ptr(f1), ptr(f2), None, None, ptr(bias), None, _lib.ACT_ELU, _lib.REDUCE_CONCAT,
             0.2, 1.0, 1.0, 0] + [ptr(o) for o in outs]
     if name == "gatmi_gat_fwd":
         tail.append(ptr(ws))
