@@ -476,7 +476,7 @@ __global__ __launch_bounds__(kGraphFwdThreads) void dense_graph_fwd_kernel(Maske
         const float f1v = a.f1[(b * N + i) * H + head];
         float mx = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < kGraphK; ++k) mx = fmaxf(fmaxf(mx, fmaxf(cur.v[k].x, cur.v[k].y)), fmaxf(cur.v[k].z, cur.v[k].w));
+        for (int k = 0; k < kGraphK; ++k) mx = raw_max3(mx, raw_max(cur.v[k].x, cur.v[k].y), raw_max(cur.v[k].z, cur.v[k].w));
         mx = row16_max(mx);
         const float cut = mx - kMaskCutoffFwd;
         // bit 4k + c of `bits`: column 64k + 4 sub + c is visited.  A visited entry is non-zero iff the row's
@@ -543,8 +543,8 @@ __global__ __launch_bounds__(kGraphFwdThreads) void dense_graph_fwd_kernel(Maske
             const float inv = empty ? 0.f : 1.0f / st.s;
             const float4 ag = f4_scale(inv, st.acc);
             if (SAVE) {
-                *reinterpret_cast<float4 *>(a.agg + row * HD + sub * 4) = ag;
-                *reinterpret_cast<float4 *>(a.pos + row * HD + sub * 4) = f4_scale(inv, st.pos);
+                store_stream4(a.agg + row * HD + sub * 4, ag);
+                store_stream4(a.pos + row * HD + sub * 4, f4_scale(inv, st.pos));
                 if (sub % LPH == 0) {
                     a.lse[row * H + head] = empty ? 0.f : st.m + logf(st.s);
                     a.q[row * H + head] = st.q * inv;
@@ -554,7 +554,246 @@ __global__ __launch_bounds__(kGraphFwdThreads) void dense_graph_fwd_kernel(Maske
             if (a.bias) r = f4_add(r, *reinterpret_cast<const float4 *>(a.bias + sub * 4));
             if (a.resid) r = f4_add(r, *reinterpret_cast<const float4 *>(a.resid + row * HD + sub * 4));
             if (a.activation != GATMI_ACT_IDENTITY) r = make_float4(act_f(r.x, a.activation), act_f(r.y, a.activation), act_f(r.z, a.activation), act_f(r.w, a.activation));
-            *reinterpret_cast<float4 *>(a.out + row * HD + sub * 4) = r;
+            store_stream4(a.out + row * HD + sub * 4, r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same kernel with the walk on eight lanes per row.  Compaction stays as above (16 lanes per row,
+// one DPP row each, four rows per wave), but a wave compacts TWO row quads before it walks, and in the
+// walk a row belongs to eight lanes of eight floats each.  For heads of 8 floats or more a lane then
+// holds whole heads' worth of one head only, so the per-head part of an entry's work (logit, LeakyReLU,
+// running maximum, exponentials: half of the walk's instructions) is no longer done twice by the two
+// float4 lanes of a head, and eight rows share every instruction instead of four.
+// LPH8 = lanes per head in the walk = dp / 8.
+// ------------------------------------------------------------------------------------------
+struct MRowState8 {
+    float m, s, q;
+    float4 acc0, acc1, pos0, pos1;
+};
+
+template <int LPH8, bool SAVE, bool SOFT>
+__device__ __forceinline__ void graph_fwd_batch8(MRowState8 &st, float slope, const uint16_t *lp, const float *bm, int N,
+                                                 const float *whs, const float *f2s, float f1v) {
+    constexpr int H = 8 / LPH8;
+    constexpr int HD = 64;
+    constexpr int U = kGraphBatch;
+    int j[U];
+    float z[U], e[U];
+    float4 v0[U], v1[U];
+    load_ids<U>(lp, j);
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        z[t] = f1v + f2s[j[t] * H];
+        v0[t] = *reinterpret_cast<const float4 *>(whs + j[t] * HD);
+        v1[t] = *reinterpret_cast<const float4 *>(whs + j[t] * HD + 4);
+        if (SOFT) e[t] = bm[min(j[t], N - 1)];
+    }
+    float mn = st.m;
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        e[t] = SOFT ? leaky(z[t], slope) + e[t] : leaky(z[t], slope);
+        mn = fmaxf(mn, e[t]);
+    }
+    const float sc = exp_neg(st.m - mn);
+    float bs = 0.f, bq = 0.f;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bacc0 = zero, bacc1 = zero, bpos0 = zero, bpos1 = zero;
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        const float p = exp_neg(e[t] - mn);
+        bs += p;
+        bacc0 = f4_fma(p, v0[t], bacc0);
+        bacc1 = f4_fma(p, v1[t], bacc1);
+        if (SAVE) {
+            const float pp = z[t] > 0.f ? p : 0.f;
+            bq += pp;
+            bpos0 = f4_fma(pp, v0[t], bpos0);
+            bpos1 = f4_fma(pp, v1[t], bpos1);
+        }
+    }
+    st.s = fmaf(st.s, sc, bs);
+    st.acc0 = f4_fma(sc, st.acc0, bacc0);
+    st.acc1 = f4_fma(sc, st.acc1, bacc1);
+    if (SAVE) {
+        st.q = fmaf(st.q, sc, bq);
+        st.pos0 = f4_fma(sc, st.pos0, bpos0);
+        st.pos1 = f4_fma(sc, st.pos1, bpos1);
+    }
+    st.m = mn;
+}
+
+constexpr int kGraphWalkRows = 8;          // rows per wave in the eight-lane walk
+constexpr int kGraph8MaxWaves = 12;        // three waves per SIMD: 168 registers per lane (two mask rows + the walk state)
+
+// waves per block: as few as finish the graph's row octets in the same number of rounds as the maximum would
+static inline int graph8_waves(int N) {
+    const int octs = (N + kGraphWalkRows - 1) / kGraphWalkRows;
+    const int rounds = (octs + kGraph8MaxWaves - 1) / kGraph8MaxWaves;
+    return (octs + rounds - 1) / rounds;
+}
+// LDS: Wh [N + pad][64] | f2 [N + pad][H] | lists [waves][8][lc] (uint16) | entry counts [waves][8] (int)
+static inline size_t graph8_fwd_lds(int N, int H, int lc, int waves) {
+    return (size_t)(N + kGraphPadRows) * (64 + H) * sizeof(float) + (size_t)waves * kGraphWalkRows * lc * sizeof(uint16_t) +
+           (size_t)waves * kGraphWalkRows * sizeof(int);
+}
+
+template <int LPH8, bool SAVE>
+__global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_fwd8_kernel(MaskedFwdArgs a, int lc) {
+    constexpr int G = 16;                  // compaction: lanes per row
+    constexpr int H = 8 / LPH8;
+    constexpr int HD = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char graph_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int sub = lane % G, grp = lane / G;
+    const int N = a.N;
+    const int NP = N + kGraphPadRows;
+    const int64_t b = blockIdx.x;
+    float *whs = reinterpret_cast<float *>(graph_smem);
+    float *f2s = whs + NP * HD;
+    uint16_t *lists = reinterpret_cast<uint16_t *>(f2s + NP * H) + wave * kGraphWalkRows * lc;      // this wave's eight lists
+    int *cnt = reinterpret_cast<int *>(reinterpret_cast<uint16_t *>(f2s + NP * H) + nwaves * kGraphWalkRows * lc) + wave * kGraphWalkRows;
+    const float *bmat = a.bias_mat + b * N * (int64_t)N;
+    // quads of this wave in order: (oct0, first half), (oct0, second half), (oct0 + nwaves * 8, first half), ...
+    MaskRow next;
+    int oct0 = wave * kGraphWalkRows;
+    if (oct0 < N) load_mask_row(next, bmat + min(oct0 + grp, N - 1) * N, N, sub);
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.Wh + b * N * (int64_t)HD);
+        for (int e = threadIdx.x; e < NP * (HD / 4); e += blockDim.x)
+            reinterpret_cast<float4 *>(whs)[e] = e < N * (HD / 4) ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float *src2 = a.f2 + b * N * (int64_t)H;
+        for (int e = threadIdx.x; e < NP * H; e += blockDim.x) f2s[e] = e < N * H ? src2[e] : -INFINITY;
+    }
+    __syncthreads();
+    const int W = (N + 31) / 32 + 1;
+    uint32_t *present_b = a.present ? a.present + b * N * (int64_t)W : nullptr;
+    // walk geometry: row r8 of the octet, lane s8 of the row
+    const int r8 = lane >> 3, s8 = lane & 7;
+    const int head8 = s8 / LPH8;
+    const float *whl = whs + s8 * 8;
+    const float *f2l = f2s + head8;
+    for (; oct0 < N; oct0 += nwaves * kGraphWalkRows) {
+        bool anysoft = false;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int row0 = oct0 + 4 * half;
+            const MaskRow cur = next;
+            {                                                // the next quad's rows travel during this quad's work
+                const int nrow0 = half == 0 ? row0 + 4 : oct0 + nwaves * kGraphWalkRows;
+                if (nrow0 < N) load_mask_row(next, bmat + min(nrow0 + grp, N - 1) * N, N, sub);
+            }
+            uint16_t *lrow = lists + (4 * half + grp) * lc;
+            if (row0 >= N) {                                 // wave-uniform: an octet's second quad beyond the graph
+                if (sub == 0) cnt[4 * half + grp] = 0;
+                continue;
+            }
+            const int i = min(row0 + grp, N - 1);
+            const bool row_ok = row0 + grp < N;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < kGraphK; ++k) mx = raw_max3(mx, raw_max(cur.v[k].x, cur.v[k].y), raw_max(cur.v[k].z, cur.v[k].w));
+            mx = row16_max(mx);
+            const float cut = mx - kMaskCutoffFwd;
+            uint32_t bits = 0;
+            bool nonzero = mx != 0.f;
+#pragma unroll
+            for (int k = 0; k < kGraphK; ++k) {
+                const float comp[4] = {cur.v[k].x, cur.v[k].y, cur.v[k].z, cur.v[k].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool present = comp[c] > cut;
+                    bits |= present ? (1u << (4 * k + c)) : 0u;
+                    nonzero |= present && comp[c] < 0.f;
+                }
+            }
+            const int cntl = __popc(bits);
+            const int total = row16_sum(cntl);
+            int pos = row16_scan(cntl) - cntl;
+            const uint64_t nzb = __ballot(nonzero && bits != 0);
+            anysoft |= nzb != 0;
+            if (present_b && row_ok) {
+                uint32_t *prow = present_b + i * W;
+#pragma unroll
+                for (int k = 0; k < kGraphK; ++k) {
+                    if (64 * k < N) {
+                        const uint32_t w = or8_to_first(((bits >> (4 * k)) & 15u) << (4 * (sub & 7)));
+                        const int wi = 2 * k + (sub >> 3);
+                        if ((sub & 7) == 0 && wi < W - 1) prow[wi] = w;
+                    }
+                }
+                if (sub == 0) prow[W - 1] = ((nzb >> (16 * grp)) & 0xffffull) != 0 ? 1u : 0u;
+            }
+            for (uint32_t rest = bits; __ballot(rest != 0) != 0;) {
+                if (rest != 0) {
+                    const int t = __ffs(rest) - 1;
+                    lrow[pos++] = (uint16_t)(64 * (t >> 2) + 4 * sub + (t & 3));
+                    rest &= rest - 1;
+                }
+            }
+            if (sub < kGraphBatch) lrow[total + sub] = (uint16_t)N;          // padding: the dummy row
+            if (sub == 0) cnt[4 * half + grp] = row_ok ? total : 0;
+        }
+        // the lists and counts are written and read by this wave only; its lanes run in lockstep
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int i = min(oct0 + r8, N - 1);
+        const bool row_ok = oct0 + r8 < N;
+        const int total = cnt[r8];
+        const uint16_t *lrow = lists + r8 * lc;
+        const float f1v = a.f1[(b * N + i) * H + head8];
+        MRowState8 st;
+        st.m = -INFINITY;
+        st.s = st.q = 0.f;
+        st.acc0 = st.acc1 = st.pos0 = st.pos1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            const float *bm_own = bmat + i * N;
+            if (anysoft) {                                // wave-uniform: biases are fetched for all of the wave's rows
+                for (int k = 0; k < total; k += kGraphBatch)
+                    graph_fwd_batch8<LPH8, SAVE, true>(st, a.slope, lrow + k, bm_own, N, whl, f2l, f1v);
+            } else {
+                for (int k = 0; k < total; k += kGraphBatch)
+                    graph_fwd_batch8<LPH8, SAVE, false>(st, a.slope, lrow + k, bm_own, N, whl, f2l, f1v);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                 // every lane is done with the lists before the next rows overwrite them
+        if (row_ok) {
+            const int64_t row = b * N + i;
+            const bool empty = !(st.s > 0.f);
+            const float inv = empty ? 0.f : 1.0f / st.s;
+            const float4 ag0 = f4_scale(inv, st.acc0), ag1 = f4_scale(inv, st.acc1);
+            float *o = nullptr;
+            if (SAVE) {
+                o = a.agg + row * HD + s8 * 8;
+                store_stream4(o, ag0);
+                store_stream4(o + 4, ag1);
+                o = a.pos + row * HD + s8 * 8;
+                store_stream4(o, f4_scale(inv, st.pos0));
+                store_stream4(o + 4, f4_scale(inv, st.pos1));
+                if (s8 % LPH8 == 0) {
+                    a.lse[row * H + head8] = empty ? 0.f : st.m + logf(st.s);
+                    a.q[row * H + head8] = st.q * inv;
+                }
+            }
+            float4 r0 = ag0, r1 = ag1;
+            if (a.bias) {
+                r0 = f4_add(r0, *reinterpret_cast<const float4 *>(a.bias + s8 * 8));
+                r1 = f4_add(r1, *reinterpret_cast<const float4 *>(a.bias + s8 * 8 + 4));
+            }
+            if (a.resid) {
+                r0 = f4_add(r0, *reinterpret_cast<const float4 *>(a.resid + row * HD + s8 * 8));
+                r1 = f4_add(r1, *reinterpret_cast<const float4 *>(a.resid + row * HD + s8 * 8 + 4));
+            }
+            if (a.activation != GATMI_ACT_IDENTITY) {
+                r0 = make_float4(act_f(r0.x, a.activation), act_f(r0.y, a.activation), act_f(r0.z, a.activation), act_f(r0.w, a.activation));
+                r1 = make_float4(act_f(r1.x, a.activation), act_f(r1.y, a.activation), act_f(r1.z, a.activation), act_f(r1.w, a.activation));
+            }
+            o = a.out + row * HD + s8 * 8;
+            store_stream4(o, r0);
+            store_stream4(o + 4, r1);
         }
     }
 }
@@ -897,8 +1136,182 @@ __global__ __launch_bounds__(kGraphFwdThreads) void dense_graph_bwd_kernel(Maske
                 r = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + sub * 4), r);
                 r = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + sub * 4), r);
             }
-            *reinterpret_cast<float4 *>(a.dWh + j * HD + sub * 4) = r;
+            store_stream4(a.dWh + j * HD + sub * 4, r);
             if (sub % LPH == 0) a.df2[j * H + head] = st.df2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The backward kernel with the walk on eight lanes per column (see dense_graph_fwd8_kernel): a wave
+// builds the lists of two column quads with 16 lanes per column, then walks eight columns at once,
+// a lane holding eight floats of its column's Wh row and of every gathered g row.  With heads of
+// eight floats the dot product <g_i, Wh_j> of a head stays inside one lane.
+// ------------------------------------------------------------------------------------------
+struct MSrcState8 {
+    float4 acc0, acc1;
+    float df2;
+};
+
+template <int LPH8, bool SOFT>
+__device__ __forceinline__ void graph_bwd_batch8(MSrcState8 &st, float slope, const uint16_t *lp, const float *bmcol, int N,
+                                                 const float *gs, const float *ss, float f2v, float4 wh0, float4 wh1) {
+    constexpr int H = 8 / LPH8;
+    constexpr int HD = 64;
+    constexpr int U = kGraphBatch;
+    int i[U];
+    float4 g0[U], g1[U];
+    float f1v[U], lsev[U], cv[U], bv[U];
+    load_ids<U>(lp, i);                                  // entries: row id | (needs its bias value) << 15
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        const bool soft = i[t] & 0x8000;
+        i[t] &= 0x7fff;
+        g0[t] = *reinterpret_cast<const float4 *>(gs + i[t] * HD);
+        g1[t] = *reinterpret_cast<const float4 *>(gs + i[t] * HD + 4);
+        const float *sp = ss + i[t] * (3 * H);
+        f1v[t] = sp[0];
+        lsev[t] = sp[H];
+        cv[t] = sp[2 * H];
+        bv[t] = 0.f;
+        if (SOFT) {
+            if (soft) bv[t] = bmcol[(uint32_t)min(i[t], N - 1) * (uint32_t)N];
+        }
+    }
+    float bdf2 = 0.f;
+    float4 bacc0 = make_float4(0.f, 0.f, 0.f, 0.f), bacc1 = bacc0;
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+        const float z = f1v[t] + f2v;
+        const float alpha = exp_neg((SOFT ? leaky(z, slope) + bv[t] : leaky(z, slope)) - lsev[t]);
+        const float dalpha = group_sum<LPH8>(dot4(g0[t], wh0) + dot4(g1[t], wh1));
+        bdf2 += alpha * (dalpha - cv[t]) * (z > 0.f ? 1.f : slope);
+        bacc0 = f4_fma(alpha, g0[t], bacc0);
+        bacc1 = f4_fma(alpha, g1[t], bacc1);
+    }
+    st.acc0 = f4_add(st.acc0, bacc0);
+    st.acc1 = f4_add(st.acc1, bacc1);
+    st.df2 += bdf2;
+}
+
+// LDS: g [N + pad][64] | stats [N + pad][3H] | bits [N][W] | lists [waves][8][lc] (uint16) | entry counts [waves][8] (int)
+static inline size_t graph8_bwd_lds(int N, int H, int lc, int waves) {
+    const int W = (N + 31) / 32 + 1;
+    return (size_t)(N + kGraphPadRows) * (64 + 3 * H) * sizeof(float) + (size_t)N * W * sizeof(uint32_t) +
+           (size_t)waves * kGraphWalkRows * lc * sizeof(uint16_t) + (size_t)waves * kGraphWalkRows * sizeof(int);
+}
+
+template <int LPH8>
+__global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(MaskedBwdArgs a, int lc) {
+    constexpr int G = 16;
+    constexpr int H = 8 / LPH8;
+    constexpr int HD = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char graph_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int sub = lane % G, grp = lane / G;
+    const int N = a.N;
+    const int NP = N + kGraphPadRows;
+    const int W = (N + 31) / 32 + 1;
+    const int64_t b = blockIdx.x;
+    float *gs = reinterpret_cast<float *>(graph_smem);                        // [NP][HD]
+    float *ss = gs + NP * HD;                                                 // [NP][3H]
+    uint32_t *ps = reinterpret_cast<uint32_t *>(ss + NP * 3 * H);             // [N][W]
+    uint16_t *lists = reinterpret_cast<uint16_t *>(ps + N * W) + wave * kGraphWalkRows * lc;      // N * W even (N % 4 == 0): 8-byte aligned
+    int *cnt = reinterpret_cast<int *>(reinterpret_cast<uint16_t *>(ps + N * W) + nwaves * kGraphWalkRows * lc) + wave * kGraphWalkRows;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.g + b * N * (int64_t)HD);
+        for (int e = threadIdx.x; e < NP * (HD / 4); e += blockDim.x)
+            reinterpret_cast<float4 *>(gs)[e] = e < N * (HD / 4) ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float *src2 = a.stats + b * N * (int64_t)(3 * H);
+        for (int e = threadIdx.x; e < NP * 3 * H; e += blockDim.x) {
+            // dummy rows: f1 = 0, lse = +inf (coefficient 0), c = 0
+            const int k = (e % (3 * H)) / H;
+            ss[e] = e < N * 3 * H ? src2[e] : (k == 1 ? INFINITY : 0.f);
+        }
+        const uint32_t *src3 = a.present + b * N * (int64_t)W;
+        for (int e = threadIdx.x; e < N * W; e += blockDim.x) ps[e] = src3[e];
+    }
+    __syncthreads();
+    const int c8 = lane >> 3, s8 = lane & 7;
+    const int head8 = s8 / LPH8;
+    const float *gl = gs + s8 * 8;
+    const float *sl = ss + head8;
+    for (int j0 = wave * kGraphWalkRows; j0 < N; j0 += nwaves * kGraphWalkRows) {
+        bool anysoft = false;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int q0 = j0 + 4 * half;
+            uint16_t *lrow = lists + (4 * half + grp) * lc;
+            if (q0 >= N) {                                // wave-uniform: the octet's second quad lies beyond the graph
+                if (sub == 0) cnt[4 * half + grp] = 0;
+                continue;
+            }
+            const int jcol = min(q0 + grp, N - 1);
+            const bool col_ok = q0 + grp < N;
+            // bit r of `bits`: destination row 16 r + sub visited column jcol; `softs`: and needs its bias value
+            uint32_t bits = 0, softs = 0;
+            const int wj = jcol >> 5, bj = jcol & 31;
+#pragma unroll
+            for (int r = 0; r < kGraphBwdRows; ++r) {
+                const int i = 16 * r + sub;
+                if (16 * r < N) {                         // uniform
+                    const int ic = min(i, N - 1);
+                    const uint32_t word = ps[ic * W + wj], flag = ps[ic * W + W - 1];
+                    const uint32_t bit = i < N ? (word >> bj) & 1u : 0u;
+                    bits |= bit << r;
+                    softs |= (bit & flag) << r;
+                }
+            }
+            const int cntl = __popc(bits);
+            const int total = row16_sum(cntl);
+            int pos = row16_scan(cntl) - cntl;
+            anysoft |= __ballot(softs != 0) != 0;
+            for (uint32_t rest = bits; __ballot(rest != 0) != 0;) {          // each lane appends its rows at its offset
+                if (rest != 0) {
+                    const int t = __ffs(rest) - 1;
+                    lrow[pos++] = (uint16_t)((16 * t + sub) | (((softs >> t) & 1u) << 15));
+                    rest &= rest - 1;
+                }
+            }
+            if (sub < kGraphBatch) lrow[total + sub] = (uint16_t)N;          // padding: the dummy row
+            if (sub == 0) cnt[4 * half + grp] = col_ok ? total : 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int jcol = min(j0 + c8, N - 1);
+        const bool col_ok = j0 + c8 < N;
+        const int64_t j = b * N + jcol;
+        const int total = cnt[c8];
+        const uint16_t *lrow = lists + c8 * lc;
+        const float f2v = a.f2[j * H + head8];
+        const float4 wh0 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + s8 * 8);
+        const float4 wh1 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + s8 * 8 + 4);
+        MSrcState8 st;
+        st.acc0 = st.acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.df2 = 0.f;
+        {
+            const float *bmcol = a.bias_mat + b * N * (int64_t)N + jcol;
+            if (anysoft) {
+                for (int k = 0; k < total; k += kGraphBatch) graph_bwd_batch8<LPH8, true>(st, a.slope, lrow + k, bmcol, N, gl, sl, f2v, wh0, wh1);
+            } else {
+                for (int k = 0; k < total; k += kGraphBatch) graph_bwd_batch8<LPH8, false>(st, a.slope, lrow + k, bmcol, N, gl, sl, f2v, wh0, wh1);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                 // every lane is done with the lists before the next columns overwrite them
+        if (col_ok) {
+            float4 r0 = st.acc0, r1 = st.acc1;
+            if (a.a1) {
+                const float d1 = a.df1[j * H + head8];
+                r0 = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + s8 * 8), r0);
+                r1 = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + s8 * 8 + 4), r1);
+                r0 = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + s8 * 8), r0);
+                r1 = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + s8 * 8 + 4), r1);
+            }
+            store_stream4(a.dWh + j * HD + s8 * 8, r0);
+            store_stream4(a.dWh + j * HD + s8 * 8 + 4, r1);
+            if (s8 % LPH8 == 0) a.df2[j * H + head8] = st.df2;
         }
     }
 }
@@ -951,6 +1364,27 @@ extern "C" int gatmi_dense_attn_fwd_masked(int64_t B, int32_t N, int32_t H, int3
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // many small graphs: one block per graph with the graph's rows resident in LDS
     const int lc = graph_list_capacity(N);
+    if (!drop && G == 16 && LPH >= 2 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch &&
+        graph8_fwd_lds(N, H, lc, graph8_waves(N)) <= kGraphFwdLdsMax) {
+        const int waves = graph8_waves(N);
+        const size_t lds = graph8_fwd_lds(N, H, lc, waves);
+        hipError_t e = hipSuccess;
+#define X(ll)                                                                                                      \
+        if (LPH == 2 * ll) {                                                                                      \
+            if (save) {                                                                                           \
+                if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_fwd8_kernel<ll, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_fwd8_kernel<ll, true>), dim3((unsigned)B), dim3(64 * waves), lds, st, a, lc); \
+            } else {                                                                                              \
+                if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_fwd8_kernel<ll, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_fwd8_kernel<ll, false>), dim3((unsigned)B), dim3(64 * waves), lds, st, a, lc); \
+            }                                                                                                     \
+            if (e != hipSuccess) return fail(GATMI_EHIP, "dense_attn_fwd_masked: %s", hipGetErrorString(e));       \
+            GATMI_LAUNCH_CHECK("dense_attn_fwd_masked (graph-resident, eight-lane walk)");                        \
+            return GATMI_OK;                                                                                      \
+        }
+        X(1) X(2) X(4) X(8)
+#undef X
+    }
     if (!drop && G == 16 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && graph_fwd_lds(N, G, H, lc) <= kGraphFwdLdsMax) {
         const size_t lds = graph_fwd_lds(N, G, H, lc);
         hipError_t e = hipSuccess;
@@ -1006,6 +1440,22 @@ extern "C" int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int3
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // many small graphs: one block per graph with the graph's rows resident in LDS
     const int lcg = graph_list_capacity(N);
+    if (!drop && G == 16 && LPH >= 2 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch &&
+        graph8_bwd_lds(N, H, lcg, graph8_waves(N)) <= kGraphFwdLdsMax) {
+        const int waves = graph8_waves(N);
+        const size_t glds = graph8_bwd_lds(N, H, lcg, waves);
+        hipError_t e = hipSuccess;
+#define X(ll)                                                                                                      \
+        if (LPH == 2 * ll) {                                                                                      \
+            if (glds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_bwd8_kernel<ll>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds); \
+            if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_bwd8_kernel<ll>), dim3((unsigned)B), dim3(64 * waves), glds, st, a, lcg); \
+            if (e != hipSuccess) return fail(GATMI_EHIP, "dense_attn_bwd_masked: %s", hipGetErrorString(e));       \
+            GATMI_LAUNCH_CHECK("dense_attn_bwd_masked (graph-resident, eight-lane walk)");                        \
+            return GATMI_OK;                                                                                      \
+        }
+        X(1) X(2) X(4) X(8)
+#undef X
+    }
     if (!drop && G == 16 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && graph_bwd_lds(N, H, lcg) <= kGraphFwdLdsMax) {
         const size_t glds = graph_bwd_lds(N, H, lcg);
         hipError_t e = hipSuccess;

@@ -15,6 +15,19 @@ __device__ __forceinline__ float exp_neg(float x) { return __builtin_amdgcn_exp2
 
 __device__ __forceinline__ float leaky(float z, float slope) { return fmaxf(z, z * slope); }
 
+// max of values read straight from memory (mask entries): fmaxf would first quiet possible signalling NaNs with
+// one extra v_max per operand; a mask holds none, and the comparisons that follow treat any NaN as "not visited"
+__device__ __forceinline__ float raw_max(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float raw_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // Cross-lane steps without LDS traffic (DPP modifiers; a __shfl is a ds_bpermute with LDS latency).
 // CTRL: 0xB1 / 0x4E swap lanes inside quads (xor 1 / xor 2), 0x141 / 0x140 mirror half rows / rows of
 // 16 lanes, 0x142 / 0x143 broadcast lane 15 / 31 of a row to the following rows, 0x100 + n takes the
