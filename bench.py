@@ -378,7 +378,14 @@ def main():
                         "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "alg_bytes_per_launch": ab, "avg_ms": round(per_step[dom], 4),
-                        "launches_per_step": ksum[dom][1] // args.steps}
+                        "launches_per_step": ksum[dom][1] // args.steps,
+                        "note": "achieved = algorithmic bytes / time: every entry is charged its full gather, so rows gathered "
+                                "many times (hubs) that L2 / Infinity Cache serve push it past what HBM itself delivers; "
+                                "traffic_* prices the bytes the counters saw leave L2"}
+            if traffic:
+                tg = traffic / (per_step[dom] * 1e-3) / 1e9
+                roofline["traffic_achieved"] = round(tg, 1)
+                roofline["traffic_frac"] = round(tg / HBM_PEAK_GBPS, 4)
         lb = layer_alg_bytes(E_rank, n_own, s=s_bytes)
         lg = lb / (ms_per_step * 1e-3) / 1e9
         impl = sum(kernel_alg_bytes(k, E_rank, n_own, s=s_bytes) for k in
