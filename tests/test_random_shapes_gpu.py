@@ -12,7 +12,8 @@ from tests.util import assert_close, dense_dropout_masks, layer_params, random_g
 
 pytestmark = pytest.mark.gpu
 DRAWS = int(os.environ.get("GATMI_SWEEP", "10"))
-KINK = 5e-7       # logits closer to LeakyReLU's kink than fp32 rounding can resolve
+KINK = 2e-6       # logits closer to LeakyReLU's kink than fp32 rounding can resolve (|f1|, |f2| reach ~10: eps * 10)
+RELU_KINK = 1e-5  # the same for the layer's pre-activation under a ReLU output (a sum of tens of O(1) terms in fp32)
 HEAD_SHAPES = [(8, 8), (1, 7), (4, 8), (2, 16), (1, 64), (8, 4), (1, 4), (16, 8), (4, 64), (2, 3), (8, 32), (1, 100)]
 
 
@@ -24,7 +25,7 @@ def _close(got, ref, what, **kw):
     """assert_close, except that a reference that is pure rounding noise (a gradient that is exactly
     zero in exact arithmetic, e.g. da1 when every row attends to one entry) only asks for ~0."""
     if ref.size and np.abs(ref).max() < 1e-9:
-        assert np.abs(got).max() < 1e-6, what
+        assert np.abs(got).max() < 1e-5, what       # fp32 noise of the logit-gradient identity (dropout scales it by 1/keep)
     else:
         assert_close(got, ref, what=what, **kw)
 
@@ -81,6 +82,16 @@ def test_sparse_layer_random_draw(seed):
                               ft_mask=None if ft_mask is None else torch.tensor(ft_mask),
                               coef_keep=1.0 - coef_drop, ft_keep=1.0 - in_drop)
     assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), what=what + " forward")
+    if activation == "relu":
+        # a pre-activation within fp32 rounding of 0 may fall on the other side of ReLU's kink than in float64:
+        # that element's gradient is then all or nothing (found by draw 758 of a 1500-draw sweep: |pre| = 1.6e-7)
+        with torch.no_grad():
+            pre = ref_torch.layer_csr(rx, rp, torch.tensor(rowptr), torch.tensor(col), "identity", reduce, residual=res,
+                                      coef_mask=None if coef_mask is None else torch.tensor(coef_mask),
+                                      ft_mask=None if ft_mask is None else torch.tensor(ft_mask),
+                                      coef_keep=1.0 - coef_drop, ft_keep=1.0 - in_drop)
+        if float(pre.abs().min()) < RELU_KINK:
+            pytest.skip("a pre-activation lies within fp32 rounding of ReLU's kink")
     dout = rng.normal(0, 1, tuple(out.shape))
     out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
     ref.backward(torch.tensor(dout))
@@ -129,6 +140,14 @@ def test_dense_layer_random_draw(seed):
                                     ft_mask=None if ft_mask is None else torch.tensor(ft_mask),
                                     coef_keep=1.0 - coef_drop, ft_keep=1.0 - in_drop)
         assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), what=what + " forward")
+        if activation == "relu":
+            with torch.no_grad():
+                pre = ref_torch.layer_dense(rx, rp, torch.tensor(bm), "identity", "concat",
+                                            coef_mask=None if coef_mask is None else torch.tensor(coef_mask),
+                                            ft_mask=None if ft_mask is None else torch.tensor(ft_mask),
+                                            coef_keep=1.0 - coef_drop, ft_keep=1.0 - in_drop)
+            if float(pre.abs().min()) < RELU_KINK:
+                continue                    # ReLU's kink, as in the sparse draw above: forward checked, gradients not comparable
         dout = rng.normal(0, 1, tuple(out.shape))
         out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
         ref.backward(torch.tensor(dout))
@@ -177,6 +196,13 @@ def test_decoder_and_bnf_random_draw(seed):
     rA = torch.tensor(A, dtype=torch.float64, requires_grad=True)
     ref = ref_torch.bnf_v2e_aggregate(rx, rA, rp)
     assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), what=what + " forward")
+    # every pair (i, j) of a graph has a logit here (no mask): one of the ~N^2 H of them within fp32 rounding of
+    # LeakyReLU's kink is common, and its gradient then legitimately takes the other slope (see _min_abs_logit)
+    z = x.reshape(B, N, F) @ p["W"].reshape(F, H * Dz)
+    zf1 = (z.reshape(B, N, H, Dz) * p["a1"]).sum(-1) + p["b1"]
+    zf2 = (z.reshape(B, N, H, Dz) * p["a2"]).sum(-1) + p["b2"]
+    if float(np.abs(zf1[:, :, None, :] + zf2[:, None, :, :]).min()) < KINK:
+        pytest.skip("a logit lies within fp32 rounding of LeakyReLU's kink")
     dout = rng.normal(0, 1, tuple(ref.shape))
     out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
     ref.backward(torch.tensor(dout))
