@@ -53,6 +53,28 @@ class _LoopbackPeers(gdist.HaloExchange):
         out.copy_(inp)
 
 
+def _kernel_breakdown(step, iters=5):
+    """Milliseconds per step of every C-ABI entry point (HIP events around each call, all launches of a step added)."""
+    from gat_amd import _lib
+    records = {}
+    raw = _lib.call
+
+    def timed(name, *args):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        raw(name, *args)
+        b.record()
+        records.setdefault(name, []).append((a, b))
+    _lib.call = timed
+    try:
+        for _ in range(iters):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        _lib.call = raw
+    return {k.replace("gatmi_", ""): round(sum(a.elapsed_time(b) for a, b in v) / iters, 3) for k, v in sorted(records.items())}
+
+
 def main():
     dev = torch.device("cuda:0")
     n_own, e_own = synth.PRODUCTS_NODES, synth.PRODUCTS_EDGES
@@ -105,6 +127,8 @@ def main():
                     estep()
                 torch.cuda.synchronize()
                 line["exchange_step_ms_links_emulated_%s" % ("overlap" if overlap else "sequential")] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
+                if not overlap:
+                    line["exchange_sequential_kernels_ms"] = _kernel_breakdown(estep)
             line["two_phase_items"] = [len(pe.items_a), len(pe.items_b), len(pe.split_ab), pe.n_slots_ab]
             line["local_entry_frac"] = round(pe.local_entries / g.nnz, 3)
             del pe, xo
