@@ -192,6 +192,8 @@ class HaloExchange:
     def _a2a(self, out, inp, out_splits, in_splits):
         """all_to_all_single (every rank calls it, also with nothing to send); buffers are staged
         through the memory the backend works on: host for gloo, device for nccl (= RCCL)."""
+        if inp.dtype == torch.bfloat16:          # moved as bytes (rows stay rows): not every backend knows bfloat16
+            inp, out = inp.view(torch.uint8), out.view(torch.uint8)
         if self.backend == "gloo" and (inp.is_cuda or out.is_cuda):
             o = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
@@ -229,15 +231,20 @@ class HaloExchange:
         """table [n_own + n_halo, width]: owned rows valid; fills the halo rows from their owners."""
         self.gather_halo_start(self.gather_halo_pack([(table, width)])).wait()
 
-    def scatter_add_halo_mark(self, tables):
+    def scatter_add_halo_mark(self, tables, wire_bf16=()):
         """Reverse direction, step 1: the halo rows of every (table, width) are final as of now on the
-        current stream (they must not change until scatter_add_halo_finish); returns a ticket."""
+        current stream (they must not change until scatter_add_halo_finish); returns a ticket.
+        wire_bf16: indices of tables whose rows travel rounded to bf16 (half the bytes; the owner widens
+        them again before adding: for storage modes that are in the bf16 error class anyway)."""
         if self.world == 1:
             return None
         pairs = []
-        for table, width in tables:
-            recv = torch.empty((self.n_send, width), dtype=table.dtype, device=table.device)
-            pairs.append((recv, table[self.n_own:]))
+        for k, (table, width) in enumerate(tables):
+            send = table[self.n_own:]
+            if k in wire_bf16 and send.is_cuda:
+                send = send.to(torch.bfloat16)
+            recv = torch.empty((self.n_send, width), dtype=send.dtype, device=table.device)
+            pairs.append((recv, send))
         return pairs, self._mark(pairs)
 
     def scatter_add_halo_start(self, ticket):
@@ -258,7 +265,7 @@ class HaloExchange:
         pend.wait()
         for (table, width), recv in zip(tables, recvs):
             if self.n_send:
-                _unpack_sum_rows(recv, self.unpack_plan, width, table)
+                _unpack_sum_rows(recv if recv.dtype == table.dtype else recv.to(table.dtype), self.unpack_plan, width, table)
 
     def scatter_add_halo(self, table, width):
         """Halo rows of table go back to their owners and are added to the owned rows."""
@@ -492,13 +499,14 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None
             return None, dW, da1, da2, db1, db2, db, None, None, None, None
         tables = [(dfeat, hd), (df2, H)]
+        wire16 = (0,) if bf16 else ()        # bf16 storage: the returned dWh rows travel as bf16 too (df2 stays fp32: 32 B per row)
         if ctx.overlap and ex.world > 1:
             sweep(pgraph.items_csc_halo, pgraph.split_csc_halo)      # the columns whose results travel
-            ticket = ex.scatter_add_halo_mark(tables)
+            ticket = ex.scatter_add_halo_mark(tables, wire16)
             sweep(pgraph.items_csc_own, pgraph.split_csc_own)        # owned columns, beside the exchange
         else:
             sweep(graph.items_csc, graph.split_csc)
-            ticket = ex.scatter_add_halo_mark(tables)
+            ticket = ex.scatter_add_halo_mark(tables, wire16)
         ex.scatter_add_halo_finish(ex.scatter_add_halo_start(ticket), tables)
         _lib.call("gatmi_gat_bwd_finalize", n, H, dp, ptr(df1), ptr(df2), ptr(a1p), ptr(a2p), ptr(dfeat), st)
         dWh = dfeat[:n]
