@@ -15,7 +15,7 @@ from tests.util import assert_close, layer_params, random_graph
 pytestmark = pytest.mark.gpu
 
 
-def _run_layer(n, F, H, D, dst, src, activation, reduce, seed, res=False, chunk=256, need_dx=True):
+def _run_layer(n, F, H, D, dst, src, activation, reduce, seed, res=False, chunk=256, need_dx=True, storage="f32"):
     from gat_amd import CSRGraph, ops
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(seed)
@@ -24,7 +24,7 @@ def _run_layer(n, F, H, D, dst, src, activation, reduce, seed, res=False, chunk=
     graph = CSRGraph.from_coo(dst, src, n, dev, chunk=chunk)
     tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
     xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=need_dx)
-    cfg = ops.make_cfg(H, D, activation=activation, reduce=reduce)
+    cfg = ops.make_cfg(H, D, activation=activation, reduce=reduce, storage=storage)
     out = ops.sparse_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], graph, cfg,
                                tp.get("W_res"), tp.get("b_res"))
     rowptr, col = ref_numpy.coo_to_csr(np.stack([dst, src], 1), n)
@@ -129,6 +129,25 @@ def test_residual_projection(H, D, activation, reduce):
     rout.backward(torch.tensor(dout, dtype=torch.float64))
     assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what="dX")
     _check_param_grads(tp, rp, ("W", "a1", "a2", "b1", "b2", "bias", "W_res", "b_res"), n)
+
+
+def test_residual_projection_with_bf16_gather_tables():
+    """Residual branch + storage="bf16": the backward pass keeps a contiguous fp32 g for the residual's weight
+    gradient next to the bf16 records the per-source kernel gathers.  Tolerance: the bf16 class (2e-2)."""
+    n, F, H, D = 260, 20, 4, 8
+    dst, src = random_graph(n, 6.0, seed=23, hubs=1, hub_deg=200)
+    x, p, tp, xt, out, rowptr, col = _run_layer(n, F, H, D, dst, src, "elu", "concat", seed=33, res=True, chunk=64, storage="bf16")
+    rp = _oracle_leaves(p, n)
+    rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    rout = ref_torch.layer_csr(rx, rp, torch.tensor(rowptr), torch.tensor(col), "elu", "concat", residual=True)
+    tol = dict(rtol=2e-2, atol_scale=2e-2)
+    assert_close(out.detach().cpu().numpy(), rout.detach().numpy(), what="forward residual bf16", **tol)
+    dout = np.random.default_rng(9).normal(0, 1, tuple(out.shape))
+    out.backward(torch.tensor(dout, dtype=torch.float32, device=out.device))
+    rout.backward(torch.tensor(dout, dtype=torch.float64))
+    assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), what="dX", **tol)
+    for k in ("W", "a1", "a2", "bias", "W_res", "b_res"):
+        assert_close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), what="d" + k, **tol)
 
 
 def test_known_answers():
