@@ -58,6 +58,7 @@ _SIGNATURES = {
     "gatmi_gat_bwd_csc": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, P, P, c_int32, c_int64, P, c_int64, P, P, P, P, P, P, P,
                                   c_float, c_float, c_float, c_uint64, P, P, P, P]),
     "gatmi_gat_bwd_finalize": (c_int, [c_int64, c_int32, c_int32, P, P, P, P, P, P]),
+    "gatmi_gat_bwd_finalize_halo": (c_int, [c_int64, c_int32, c_int32, P, P, P, P, P, P, P, P, P, P]),
     "gatmi_dense_attn_fwd": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, c_int32, c_float,
                                      c_float, c_float, c_uint64, P, P, P, P, P, P]),
     "gatmi_dense_attn_bwd": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, P, P, c_float,

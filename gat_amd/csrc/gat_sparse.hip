@@ -537,6 +537,38 @@ __global__ __launch_bounds__(256) void gat_bwd_finalize_kernel(int64_t n, const 
     }
 }
 
+// The same step with the peers' contributions taken in on the way (row-partitioned runs): row r first adds
+// the rows recv[pos[k]], k in [rptr[r], rptr[r+1]), that the reverse halo exchange returned for it -- in
+// list order, so the sum is the one gatmi_halo_unpack_sum forms -- to dfeat and df2, then the logit terms.
+// One pass over the owned rows instead of an unpack pass plus a finalize pass.
+template <int G, int LPH>
+__global__ __launch_bounds__(256) void gat_bwd_finalize_halo_kernel(int64_t n, const float *df1, float *df2, const float *a1, const float *a2,
+                                                                     float *dfeat, const int64_t *rptr, const int64_t *pos,
+                                                                     const float *recv_feat, const float *recv_df2) {
+    constexpr int RPW = 64 / G;
+    constexpr int H = G / LPH;
+    constexpr int HD = 4 * G;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G, grp = lane / G;
+    const int head = sub / LPH;
+    const float4 a1v = *reinterpret_cast<const float4 *>(a1 + sub * 4);
+    const float4 a2v = *reinterpret_cast<const float4 *>(a2 + sub * 4);
+    const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+    for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp; row < n; row += stride) {
+        float4 r = *reinterpret_cast<const float4 *>(dfeat + row * HD + sub * 4);
+        float d2 = df2[row * H + head];
+        for (int64_t k = rptr[row]; k < rptr[row + 1]; ++k) {
+            const int64_t p = pos[k];
+            r = f4_add(r, *reinterpret_cast<const float4 *>(recv_feat + p * HD + sub * 4));
+            d2 += recv_df2[p * H + head];
+        }
+        r = f4_fma(df1[row * H + head], a1v, r);
+        r = f4_fma(d2, a2v, r);
+        *reinterpret_cast<float4 *>(dfeat + row * HD + sub * 4) = r;
+        if (sub % LPH == 0) df2[row * H + head] = d2;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side dispatch over (G, LPH)
 // ------------------------------------------------------------------------------------------
@@ -625,9 +657,37 @@ static int launch_bwd_finalize(int64_t n, const float *df1, const float *df2, co
     return GATMI_OK;
 }
 
+template <int G, int LPH>
+static int launch_bwd_finalize_halo(int64_t n, const float *df1, float *df2, const float *a1, const float *a2, float *dfeat,
+                                    const int64_t *rptr, const int64_t *pos, const float *recv_feat, const float *recv_df2, hipStream_t st) {
+    const int64_t per_block = 4 * (64 / G);
+    const unsigned nb = (unsigned)std::min<int64_t>(8192, std::max<int64_t>(1, (n + per_block - 1) / per_block));
+    hipLaunchKernelGGL((gat_bwd_finalize_halo_kernel<G, LPH>), dim3(nb), dim3(256), 0, st, n, df1, df2, a1, a2, dfeat, rptr, pos, recv_feat, recv_df2);
+    GATMI_LAUNCH_CHECK("gat_bwd_finalize_halo");
+    return GATMI_OK;
+}
+
 }  // namespace gatmi
 
 using namespace gatmi;
+
+extern "C" int gatmi_gat_bwd_finalize_halo(int64_t n, int32_t H, int32_t dp, const float *df1, float *df2,
+                                           const float *a1, const float *a2, float *dfeat,
+                                           const int64_t *rptr, const int64_t *pos, const float *recv_dfeat, const float *recv_df2,
+                                           void *stream) {
+    int G, LPH;
+    int rc = check_shape(H, dp, &G, &LPH);
+    if (rc) return rc;
+    GATMI_REQUIRE(n >= 0, GATMI_EINVAL, "gat_bwd_finalize_halo: negative size");
+    if (n == 0) return GATMI_OK;
+    GATMI_REQUIRE(df1 && df2 && a1 && a2 && dfeat && rptr && pos && recv_dfeat && recv_df2, GATMI_EINVAL, "gat_bwd_finalize_halo: null pointer");
+    GATMI_REQUIRE_ALIGNED(a1); GATMI_REQUIRE_ALIGNED(a2); GATMI_REQUIRE_ALIGNED(dfeat); GATMI_REQUIRE_ALIGNED(recv_dfeat);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define X(gg, l) if (G == gg && LPH == l) return launch_bwd_finalize_halo<gg, l>(n, df1, df2, a1, a2, dfeat, rptr, pos, recv_dfeat, recv_df2, st);
+    GATMI_FOR_SHAPES(X)
+#undef X
+    return fail(GATMI_EUNSUPPORTED, "gat_bwd_finalize_halo: no kernel for H=%d dp=%d", H, dp);
+}
 
 extern "C" int gatmi_gat_bwd_finalize(int64_t n, int32_t H, int32_t dp, const float *df1, const float *df2,
                                       const float *a1, const float *a2, float *dfeat, void *stream) {

@@ -138,6 +138,11 @@ class HaloExchange:
         rptr = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=self.device)
         rptr[1:] = torch.cumsum(counts, 0)
         self.unpack_plan = (rows.contiguous(), rptr, order.contiguous())
+        # the same lists with a range for EVERY owned row (empty for rows nobody reads): gatmi_gat_bwd_finalize_halo
+        full = torch.zeros(self.n_own + 1, dtype=torch.int64, device=self.device)
+        if self.n_send:
+            full[1:] = torch.cumsum(torch.bincount(self.send_idx, minlength=self.n_own), 0)
+        self.row_ptr_all = full
         self._comm_stream = None
         self.timings = None          # list of (start event, end event, bytes sent, bytes received) when enabled
 
@@ -266,6 +271,24 @@ class HaloExchange:
         for (table, width), recv in zip(tables, recvs):
             if self.n_send:
                 _unpack_sum_rows(recv if recv.dtype == table.dtype else recv.to(table.dtype), self.unpack_plan, width, table)
+
+    def scatter_finalize(self, pend, dfeat, df2, df1, a1p, a2p, H, dp):
+        """Step 3 of the layer's backward exchange fused with its last step: waits for the reverse exchange of
+        (dfeat [.., H*dp], df2 [.., H]) and, in one pass over the owned rows, adds the returned rows in
+        fixed order and then the logit terms df1.a1 + df2.a2 (gatmi_gat_bwd_finalize_halo)."""
+        n = self.n_own
+        st = _lib.current_stream()
+        if self.world == 1 or self.n_send == 0:
+            if self.world > 1:
+                pend.wait()
+            _lib.call("gatmi_gat_bwd_finalize", n, H, dp, ptr(df1), ptr(df2), ptr(a1p), ptr(a2p), ptr(dfeat), st)
+            return
+        recv_feat, recv_df2 = pend.recvs
+        pend.wait()
+        if recv_feat.dtype != dfeat.dtype:
+            recv_feat = recv_feat.to(dfeat.dtype)       # bf16 on the wire: widened before the sum
+        _lib.call("gatmi_gat_bwd_finalize_halo", n, H, dp, ptr(df1), ptr(df2), ptr(a1p), ptr(a2p), ptr(dfeat),
+                  ptr(self.row_ptr_all), ptr(self.unpack_plan[2]), ptr(recv_feat), ptr(recv_df2), st)
 
     def scatter_add_halo(self, table, width):
         """Halo rows of table go back to their owners and are added to the owned rows."""
@@ -507,8 +530,7 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         else:
             sweep(graph.items_csc, graph.split_csc)
             ticket = ex.scatter_add_halo_mark(tables, wire16)
-        ex.scatter_add_halo_finish(ex.scatter_add_halo_start(ticket), tables)
-        _lib.call("gatmi_gat_bwd_finalize", n, H, dp, ptr(df1), ptr(df2), ptr(a1p), ptr(a2p), ptr(dfeat), st)
+        ex.scatter_finalize(ex.scatter_add_halo_start(ticket), dfeat, df2, df1, a1p, a2p, H, dp)
         dWh = dfeat[:n]
         dx, dW, da1, da2, db1, db2, _ = ops._project_backward(x, Wp, None, feat, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
         db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None

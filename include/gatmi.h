@@ -296,6 +296,16 @@ int gatmi_to_bf16_records(const float *src, const float *f2, int64_t n, int32_t 
 int gatmi_gat_bwd_finalize(int64_t n, int32_t H, int32_t dp, const float *df1, const float *df2,
                            const float *a1, const float *a2, float *dfeat, void *stream);
 
+/* gatmi_halo_unpack_sum on dfeat and df2 followed by gatmi_gat_bwd_finalize, in one pass over the owned
+ * rows (no counterpart in the reference: row-partitioned runs): owned row r first takes in the rows
+ * recv_dfeat[pos[k], :] / recv_df2[pos[k], :], k in [rptr[r], rptr[r+1]), that the reverse halo exchange
+ * returned for it (list order: the sums are those of gatmi_halo_unpack_sum), then the logit terms.
+ *   rptr [n + 1] over ALL owned rows (rows nobody read have an empty range); df2 is updated in place. */
+int gatmi_gat_bwd_finalize_halo(int64_t n, int32_t H, int32_t dp, const float *df1, float *df2,
+                                const float *a1, const float *a2, float *dfeat,
+                                const int64_t *rptr, const int64_t *pos, const float *recv_dfeat, const float *recv_df2,
+                                void *stream);
+
 /* Batched dense masked attention (small graphs).  Replaces utils/layers.py:16-25,34 on
  * [B, N, *] tensors with the additive bias_mat [B, N, N] of utils/process.py:14-25 (any additive
  * values, not only 0 / -1e9).
