@@ -185,3 +185,37 @@ def test_rccl_initialises_and_runs_the_collective_forms_on_one_rank():
     lists on device rows and on staged int64 ids, all_reduce SUM / MAX, barrier)."""
     from tests.util import run_ranks
     run_ranks(_nccl_worker, 1, timeout=240)
+
+
+@pytest.mark.parametrize("H,D", [(8, 8), (2, 16), (1, 4)])
+def test_fused_halo_finalize_equals_unpack_then_finalize(H, D):
+    """gatmi_gat_bwd_finalize_halo against gatmi_halo_unpack_sum (on dWh and on df2) followed by
+    gatmi_gat_bwd_finalize, through the C ABI: same terms in the same order, so bit-identical; rows that no
+    peer read (empty ranges) and rows several peers returned are both in the lists."""
+    from gat_amd import _lib
+    from gat_amd._lib import ptr
+    dev = torch.device("cuda:0")
+    n, n_send, hd = 500, 1300, H * D
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    send_idx = torch.randint(0, n - 40, (n_send,), generator=gen).to(dev)           # the last 40 rows are read by nobody
+    order = torch.argsort(send_idx, stable=True)
+    rows, counts = torch.unique_consecutive(send_idx[order], return_counts=True)
+    rptr = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=dev)
+    rptr[1:] = torch.cumsum(counts, 0)
+    full = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    full[1:] = torch.cumsum(torch.bincount(send_idx, minlength=n), 0)
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(dev)
+    dfeat0, df20, df1 = rnd(n, hd), rnd(n, H), rnd(n, H)
+    recv_feat, recv_df2 = rnd(n_send, hd), rnd(n_send, H)
+    a1, a2 = rnd(hd), rnd(hd)
+    st = _lib.current_stream()
+    want_f, want_2 = dfeat0.clone(), df20.clone()
+    _lib.call("gatmi_halo_unpack_sum", ptr(recv_feat), ptr(rows), ptr(rptr), ptr(order), rows.numel(), hd, ptr(want_f), st)
+    _lib.call("gatmi_halo_unpack_sum", ptr(recv_df2), ptr(rows), ptr(rptr), ptr(order), rows.numel(), H, ptr(want_2), st)
+    _lib.call("gatmi_gat_bwd_finalize", n, H, D, ptr(df1), ptr(want_2), ptr(a1), ptr(a2), ptr(want_f), st)
+    got_f, got_2 = dfeat0.clone(), df20.clone()
+    _lib.call("gatmi_gat_bwd_finalize_halo", n, H, D, ptr(df1), ptr(got_2), ptr(a1), ptr(a2), ptr(got_f),
+              ptr(full), ptr(order), ptr(recv_feat), ptr(recv_df2), st)
+    torch.cuda.synchronize()
+    assert torch.equal(got_2, want_2) and torch.equal(got_f, want_f)
+    assert not torch.equal(got_f, dfeat0)
