@@ -381,7 +381,7 @@ __device__ __forceinline__ void graph_fwd_batch(MRowState &st, float slope, cons
 }
 
 constexpr int kGraphFwdThreads = 1024;
-constexpr size_t kGraphFwdLdsMax = 150 * 1024;
+constexpr size_t kGraphFwdLdsMax = 160 * 1024;          // a workgroup may hold all of a CU's LDS
 
 // list capacity per row: every column, plus one batch of padding, as whole batches
 static inline int graph_list_capacity(int N) { return (N + 2 * kGraphBatch - 1) / kGraphBatch * kGraphBatch; }
@@ -814,6 +814,11 @@ struct MaskedBwdArgs {
     float *dWh, *df2;
     float slope, coef_keep, feat_keep;
     uint64_t seed;
+    // fused per-destination step (dense_graph_bwd8_kernel<.., true>): g, stats and df1 are formed from these while
+    // the graph is staged, instead of being read from arrays an earlier launch wrote
+    const float *dout, *out, *agg, *pos, *q, *f1, *lse, *bias;
+    float *g_out, *df1_out, *dbias_ws;
+    int activation;
 };
 
 struct MSrcState {
@@ -1201,7 +1206,7 @@ static inline size_t graph8_bwd_lds(int N, int H, int lc, int waves) {
            (size_t)waves * kGraphWalkRows * lc * sizeof(uint16_t) + (size_t)waves * kGraphWalkRows * sizeof(int);
 }
 
-template <int LPH8>
+template <int LPH8, bool FUSED>
 __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(MaskedBwdArgs a, int lc) {
     constexpr int G = 16;
     constexpr int H = 8 / LPH8;
@@ -1219,7 +1224,7 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
     uint32_t *ps = reinterpret_cast<uint32_t *>(ss + NP * 3 * H);             // [N][W]
     uint16_t *lists = reinterpret_cast<uint16_t *>(ps + N * W) + wave * kGraphWalkRows * lc;      // N * W even (N % 4 == 0): 8-byte aligned
     int *cnt = reinterpret_cast<int *>(reinterpret_cast<uint16_t *>(ps + N * W) + nwaves * kGraphWalkRows * lc) + wave * kGraphWalkRows;
-    {
+    if (!FUSED) {
         const float4 *src = reinterpret_cast<const float4 *>(a.g + b * N * (int64_t)HD);
         for (int e = threadIdx.x; e < NP * (HD / 4); e += blockDim.x)
             reinterpret_cast<float4 *>(gs)[e] = e < N * (HD / 4) ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1229,6 +1234,83 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
             const int k = (e % (3 * H)) / H;
             ss[e] = e < N * 3 * H ? src2[e] : (k == 1 ? INFINITY : 0.f);
         }
+    } else {
+        // The per-destination step of the backward pass (gat_bwd_node_kernel) done while the graph is staged:
+        // g = dOut * activation'(pre), c = <g, agg>, df1 = (1 - slope)(<g, pos> - c q) per head, four rows per wave
+        // with 16 lanes per row; g and {f1, lse, c} go straight into LDS, df1 (and g, if asked for) to memory,
+        // the column sums of g (the bias gradient) to one partial row per graph.
+        constexpr int LPH = 2 * LPH8;                   // float4 lanes per head
+        const int head = sub / LPH;
+        const float4 biasv = a.bias ? *reinterpret_cast<const float4 *>(a.bias + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+        // four rows of the wave's share at a time: their twelve 16-byte loads are issued together (one block per CU:
+        // nothing else would cover the latency of a row-by-row walk)
+        constexpr int SR = 4;
+        for (int r0 = wave * 4 + grp; r0 < NP; r0 += SR * nwaves * 4) {
+            float4 dv[SR], av[SR], pv[SR], ov[SR];
+#pragma unroll
+            for (int u = 0; u < SR; ++u) {
+                const int r = r0 + u * nwaves * 4;
+                const int64_t row = b * N + min(r, N - 1);
+                dv[u] = load_stream4(a.dout + row * HD + sub * 4);
+                av[u] = load_stream4(a.agg + row * HD + sub * 4);
+                pv[u] = load_stream4(a.pos + row * HD + sub * 4);
+                ov[u] = a.out ? *reinterpret_cast<const float4 *>(a.out + row * HD + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < SR; ++u) {
+                const int r = r0 + u * nwaves * 4;
+                if (r >= NP) break;
+                float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+                float f1v = 0.f, lsev = INFINITY, c = 0.f;      // dummy rows: coefficient exactly 0
+                if (r < N) {
+                    const int64_t row = b * N + r;
+                    gv = dv[u];
+                    const float4 ag = av[u], po = pv[u];
+                    if (a.activation != GATMI_ACT_IDENTITY) {
+                        if (a.out) {                          // a residual was added: the derivative comes from the saved output
+                            gv.x *= act_grad_from_out(ov[u].x, a.activation);
+                            gv.y *= act_grad_from_out(ov[u].y, a.activation);
+                            gv.z *= act_grad_from_out(ov[u].z, a.activation);
+                            gv.w *= act_grad_from_out(ov[u].w, a.activation);
+                        } else {
+                            const float4 pre = f4_add(ag, biasv);
+                            gv.x *= act_grad_from_pre(pre.x, a.activation);
+                            gv.y *= act_grad_from_pre(pre.y, a.activation);
+                            gv.z *= act_grad_from_pre(pre.z, a.activation);
+                            gv.w *= act_grad_from_pre(pre.w, a.activation);
+                        }
+                    }
+                    c = group_sum<LPH>(dot4(gv, ag));
+                    const float gp = group_sum<LPH>(dot4(gv, po));
+                    f1v = a.f1[row * H + head];
+                    lsev = a.lse[row * H + head];
+                    if (sub % LPH == 0) a.df1_out[row * H + head] = (1.0f - a.slope) * (gp - c * a.q[row * H + head]);
+                    if (a.g_out) store_stream4(a.g_out + row * HD + sub * 4, gv);
+                    gsum = f4_add(gsum, gv);
+                }
+                *reinterpret_cast<float4 *>(gs + r * HD + sub * 4) = gv;
+                if (sub % LPH == 0) {
+                    ss[r * 3 * H + head] = f1v;
+                    ss[r * 3 * H + H + head] = lsev;
+                    ss[r * 3 * H + 2 * H + head] = c;
+                }
+            }
+        }
+        if (a.dbias_ws) {
+            // lanes with equal `sub` across the block, summed in a fixed order through the (not yet used) list area
+            float4 *red = reinterpret_cast<float4 *>(reinterpret_cast<uint16_t *>(ps + N * W));
+            red[threadIdx.x] = gsum;
+            __syncthreads();
+            if (threadIdx.x < G) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = threadIdx.x; i < (int)blockDim.x; i += G) t = f4_add(t, red[i]);
+                *reinterpret_cast<float4 *>(a.dbias_ws + b * HD + threadIdx.x * 4) = t;
+            }
+            __syncthreads();                              // the list area is free again
+        }
+    }
+    {
         const uint32_t *src3 = a.present + b * N * (int64_t)W;
         for (int e = threadIdx.x; e < N * W; e += blockDim.x) ps[e] = src3[e];
     }
@@ -1303,7 +1385,7 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
         if (col_ok) {
             float4 r0 = st.acc0, r1 = st.acc1;
             if (a.a1) {
-                const float d1 = a.df1[j * H + head8];
+                const float d1 = (FUSED ? a.df1_out : a.df1)[j * H + head8];
                 r0 = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + s8 * 8), r0);
                 r1 = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + s8 * 8 + 4), r1);
                 r0 = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + s8 * 8), r0);
@@ -1314,6 +1396,14 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
             if (s8 % LPH8 == 0) a.df2[j * H + head8] = st.df2;
         }
     }
+}
+
+// out[c] = sum over the per-graph partial rows ws[b][c] (fixed order: reproducible)
+__global__ void graph_dbias_sum_kernel(const float *ws, int rows, int width, float *out) {
+    const int c = blockIdx.x * kSumCols + threadIdx.x;
+    const bool ok = c < width;
+    const float t = block_column_sum(rows, [&](int r) { return ok ? ws[(int64_t)r * width + c] : 0.f; });
+    if (ok && threadIdx.y == 0) out[c] = t;
 }
 
 // (G, LPH) pairs built: rows of 32..256 floats (narrower rows leave most of a wave idle in the
@@ -1447,8 +1537,8 @@ extern "C" int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int3
         hipError_t e = hipSuccess;
 #define X(ll)                                                                                                      \
         if (LPH == 2 * ll) {                                                                                      \
-            if (glds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_bwd8_kernel<ll>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds); \
-            if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_bwd8_kernel<ll>), dim3((unsigned)B), dim3(64 * waves), glds, st, a, lcg); \
+            if (glds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_bwd8_kernel<ll, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds); \
+            if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_bwd8_kernel<ll, false>), dim3((unsigned)B), dim3(64 * waves), glds, st, a, lcg); \
             if (e != hipSuccess) return fail(GATMI_EHIP, "dense_attn_bwd_masked: %s", hipGetErrorString(e));       \
             GATMI_LAUNCH_CHECK("dense_attn_bwd_masked (graph-resident, eight-lane walk)");                        \
             return GATMI_OK;                                                                                      \
@@ -1483,4 +1573,69 @@ extern "C" int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int3
     GATMI_MASKED_SHAPES(X)
 #undef X
     return fail(GATMI_EUNSUPPORTED, "dense_attn_bwd_masked: no kernel for H=%d dp=%d", H, dp);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward for batches of many small graphs with the per-destination step fused in
+// ------------------------------------------------------------------------------------------
+static bool graph_fused_shape(int64_t B, int32_t N, int G, int LPH, int H, float coef_keep, float feat_keep) {
+    const bool drop = coef_keep < 1.f || feat_keep < 1.f;
+    return !drop && G == 16 && LPH >= 2 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && B <= 0x7fffffff &&
+           graph8_bwd_lds(N, H, graph_list_capacity(N), graph8_waves(N)) <= kGraphFwdLdsMax;
+}
+
+extern "C" int gatmi_dense_attn_bwd_fused_ok(int64_t B, int32_t N, int32_t H, int32_t dp, float coef_keep, float feat_keep) {
+    if (H <= 0 || dp < 4 || !is_pow2(dp) || !is_pow2(H) || (int64_t)H * dp > 256) return 0;
+    return graph_fused_shape(B, N, H * dp / 4, dp / 4, H, coef_keep, feat_keep) ? 1 : 0;
+}
+
+extern "C" size_t gatmi_dense_attn_bwd_fused_ws_floats(int64_t B, int32_t H, int32_t dp) {
+    return B <= 0 ? 0 : (size_t)B * (size_t)H * dp;
+}
+
+extern "C" int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32_t dp,
+                                          const float *dout, const float *out, const float *agg, const float *pos,
+                                          const float *q, const float *f1, const float *lse, const float *bias, int32_t activation,
+                                          const float *Wh, const float *f2, const float *bias_mat, const uint32_t *present,
+                                          const float *a1, const float *a2, float slope,
+                                          float *g, float *df1, float *dbias, float *ws,
+                                          float *dWh, float *df2, void *stream) {
+    int G, LPH;
+    int rc = masked_check(B, N, H, dp, &G, &LPH, "dense_attn_bwd_fused");
+    if (rc) return rc;
+    if (B == 0 || N == 0) return GATMI_OK;
+    GATMI_REQUIRE(graph_fused_shape(B, N, G, LPH, H, 1.f, 1.f), GATMI_EUNSUPPORTED,
+                  "dense_attn_bwd_fused: B=%lld N=%d H=%d dp=%d is not a shape of the graph-resident kernels (ask gatmi_dense_attn_bwd_fused_ok)",
+                  (long long)B, N, H, dp);
+    GATMI_REQUIRE(dout && agg && pos && q && f1 && lse && Wh && f2 && bias_mat && present && df1 && dWh && df2, GATMI_EINVAL, "dense_attn_bwd_fused: null pointer");
+    GATMI_REQUIRE((a1 == nullptr) == (a2 == nullptr), GATMI_EINVAL, "dense_attn_bwd_fused: a1 and a2 go together");
+    GATMI_REQUIRE(!dbias || ws, GATMI_EINVAL, "dense_attn_bwd_fused: dbias needs ws (gatmi_dense_attn_bwd_fused_ws_floats)");
+    GATMI_REQUIRE(act_known(activation), GATMI_EUNSUPPORTED, "dense_attn_bwd_fused: activation %d", activation);
+    GATMI_REQUIRE_ALIGNED(dout); GATMI_REQUIRE_ALIGNED(out); GATMI_REQUIRE_ALIGNED(agg); GATMI_REQUIRE_ALIGNED(pos); GATMI_REQUIRE_ALIGNED(bias);
+    GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(g); GATMI_REQUIRE_ALIGNED(dWh); GATMI_REQUIRE_ALIGNED(a1); GATMI_REQUIRE_ALIGNED(a2); GATMI_REQUIRE_ALIGNED(ws);
+    MaskedBwdArgs a{};
+    a.B = B; a.N = N; a.Wh = Wh; a.f2 = f2; a.bias_mat = bias_mat; a.a1 = a1; a.a2 = a2; a.present = present;
+    a.dWh = dWh; a.df2 = df2; a.slope = slope; a.coef_keep = 1.f; a.feat_keep = 1.f; a.seed = 0;
+    a.dout = dout; a.out = out; a.agg = agg; a.pos = pos; a.q = q; a.f1 = f1; a.lse = lse; a.bias = out ? nullptr : bias;
+    a.g_out = g; a.df1_out = df1; a.dbias_ws = dbias ? ws : nullptr; a.activation = activation;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int lc = graph_list_capacity(N);
+    const int waves = graph8_waves(N);
+    const size_t lds = graph8_bwd_lds(N, H, lc, waves);
+    hipError_t e = hipSuccess;
+#define X(ll)                                                                                                      \
+    if (LPH == 2 * ll) {                                                                                          \
+        if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_bwd8_kernel<ll, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_bwd8_kernel<ll, true>), dim3((unsigned)B), dim3(64 * waves), lds, st, a, lc); \
+        if (e != hipSuccess) return fail(GATMI_EHIP, "dense_attn_bwd_fused: %s", hipGetErrorString(e));               \
+        GATMI_LAUNCH_CHECK("dense_attn_bwd_fused");                                                                   \
+    }
+    X(1) X(2) X(4) X(8)
+#undef X
+    if (dbias) {
+        const int hd = H * dp;
+        hipLaunchKernelGGL(graph_dbias_sum_kernel, dim3((hd + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, ws, (int)B, hd, dbias);
+        GATMI_LAUNCH_CHECK("dense_attn_bwd_fused dbias");
+    }
+    return GATMI_OK;
 }

@@ -369,17 +369,31 @@ class DenseGATLayerFn(torch.autograd.Function):
         hd = H * dp
         n = B * N
         st = _lib.current_stream()
-        dout = _pad_last(dout.reshape(n, H, D), D, dp).reshape(n, hd)
-        g = _new((n, hd), x2)
-        stats = _new((n, 3 * H), x2)
+        dout = _pad_last(dout.reshape(n, H, D), D, dp).reshape(n, hd).contiguous()
         df1 = _new((n, H), x2)
         dbias = _new((hd,), x2)
+        dWh = _new((n, hd), x2)
+        df2 = _new((n, H), x2)
+        if ctx.present is not None and _lib.lib.gatmi_dense_attn_bwd_fused_ok(B, N, H, dp, cfg.coef_keep, cfg.feat_keep):
+            # batches of many small graphs: the block that owns a graph forms g, the row statistics and df1 of its
+            # nodes while it stages them (no per-destination launch, no round trip of g / stats through memory)
+            g = _new((n, hd), x2) if ctx.has_res else None          # only the residual branch reads g afterwards
+            ws = _new((_lib.lib.gatmi_dense_attn_bwd_fused_ws_floats(B, H, dp),), x2)
+            _lib.call("gatmi_dense_attn_bwd_fused", B, N, H, dp, ptr(dout), ptr(out) if ctx.has_res else None, ptr(agg), ptr(pos),
+                      ptr(q), ptr(f1), ptr(lse), ptr(biasp), _ACT[cfg.activation], ptr(Wh), ptr(f2), ptr(bias_mat), ptr(ctx.present),
+                      ptr(a1p), ptr(a2p), cfg.slope, ptr(g), ptr(df1), ptr(dbias), ptr(ws), ptr(dWh), ptr(df2), st)
+            dx, dW, da1, da2, db1, db2, dWr = _project_backward(x2, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
+            if dx is not None:
+                dx = dx.reshape(B, N, -1)
+            db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None
+            dbr = dbias.reshape(H, dp)[:, :D] if ctx.has_res else None
+            return dx, dW, da1, da2, db1, db2, db, dWr, dbr, None, None
+        g = _new((n, hd), x2)
+        stats = _new((n, 3 * H), x2)
         ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, dp),), x2)
         _lib.call("gatmi_gat_bwd_node", n, H, dp, ptr(dout), ptr(out) if ctx.has_res else None, ptr(agg), ptr(pos), ptr(q), ptr(f1),
                   ptr(lse), ptr(biasp), _ACT[cfg.activation], _lib.REDUCE_CONCAT, cfg.slope, ptr(g), hd, None, 0, ptr(stats), 3 * H, ptr(df1),
                   ptr(dbias), ptr(ws), st)
-        dWh = _new((n, hd), x2)
-        df2 = _new((n, H), x2)
         if ctx.present is not None:
             _lib.call("gatmi_dense_attn_bwd_masked", B, N, H, dp, ptr(g), ptr(stats), ptr(Wh), ptr(f2), ptr(bias_mat),
                       ptr(df1), ptr(a1p), ptr(a2p), ptr(ctx.present), cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,

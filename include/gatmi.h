@@ -353,6 +353,23 @@ int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int32_t dp,
                                 float slope, float coef_keep, float feat_keep, uint64_t seed,
                                 float *dWh, float *df2, void *stream);
 
+/* gatmi_gat_bwd_node and gatmi_dense_attn_bwd_masked in one launch, for the shapes the graph-resident list
+ * kernels cover (batches of at least 256 graphs of 4..320 nodes, N % 4 == 0, rows of 64 floats, heads of at
+ * least 8, no dropout: gatmi_dense_attn_bwd_fused_ok says 1): the block that owns a graph forms g, the row
+ * statistics and df1 of its nodes while it stages them, so they make no round trip through memory and one
+ * launch per step goes away.  Arguments as in those two calls; g may be NULL (it is only needed by a residual
+ * branch), dbias may be NULL, ws: gatmi_dense_attn_bwd_fused_ws_floats(B, H, dp) floats when dbias is given.
+ * Other shapes: GATMI_EUNSUPPORTED (use the two calls). */
+int gatmi_dense_attn_bwd_fused_ok(int64_t B, int32_t N, int32_t H, int32_t dp, float coef_keep, float feat_keep);
+size_t gatmi_dense_attn_bwd_fused_ws_floats(int64_t B, int32_t H, int32_t dp);
+int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32_t dp,
+                               const float *dout, const float *out, const float *agg, const float *pos,
+                               const float *q, const float *f1, const float *lse, const float *bias, int32_t activation,
+                               const float *Wh, const float *f2, const float *bias_mat, const uint32_t *present,
+                               const float *a1, const float *a2, float slope,
+                               float *g, float *df1, float *dbias, float *ws,
+                               float *dWh, float *df2, void *stream);
+
 /* Brain-network variant of the attention step: the inner loop body of attn_e2v_BNF_V2
  * (utils/layers.py:174-179) with the coefficients of attn_v2e_BNF_V2 (:229-237), for H heads that
  * share X and the weighted adjacency A but own their projection (f1, f2) and the scalars m1, m2
