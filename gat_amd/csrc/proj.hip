@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void xt_gemm_kernel(const float *X, int64_t n,
 // Block (bx, by, bz): node chunks bx, bx+gridDim.x, ...; features [128*by, +64*FS); columns [64*bz, +64).
 // ------------------------------------------------------------------------------------------
 template <int FS>
-__global__ __launch_bounds__(256, FS == 1 ? 3 : 2) void xt_gemm_lines_kernel(const float *X, int64_t n, int F, int64_t ldx,
+__global__ __launch_bounds__(256, 3) void xt_gemm_lines_kernel(const float *X, int64_t n, int F, int64_t ldx,
                                                              const float *dY, int hd, float *ws) {
     __shared__ float red[64 * FS * 65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
