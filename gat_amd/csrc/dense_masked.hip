@@ -1406,6 +1406,16 @@ __global__ void graph_dbias_sum_kernel(const float *ws, int rows, int width, flo
     if (ok && threadIdx.y == 0) out[c] = t;
 }
 
+// first stage for many graphs: block (bx, by) sums rows [by * per, (by + 1) * per) into out[by][c]
+constexpr int kDbiasStageRows = 64;
+__global__ void graph_dbias_stage_kernel(const float *ws, int rows, int width, float *out) {
+    const int c = blockIdx.x * kSumCols + threadIdx.x;
+    const bool ok = c < width;
+    const int r0 = blockIdx.y * kDbiasStageRows;
+    const float t = block_column_sum(min(kDbiasStageRows, rows - r0), [&](int r) { return ok ? ws[(int64_t)(r0 + r) * width + c] : 0.f; });
+    if (ok && threadIdx.y == 0) out[(int64_t)blockIdx.y * width + c] = t;
+}
+
 // (G, LPH) pairs built: rows of 32..256 floats (narrower rows leave most of a wave idle in the
 // compaction; those shapes stay with the matrix-core kernels)
 #define GATMI_MASKED_SHAPES(X) X(8, 1) X(8, 2) X(8, 4) X(8, 8) X(16, 1) X(16, 2) X(16, 4) X(16, 8) X(16, 16) \
@@ -1590,7 +1600,8 @@ extern "C" int gatmi_dense_attn_bwd_fused_ok(int64_t B, int32_t N, int32_t H, in
 }
 
 extern "C" size_t gatmi_dense_attn_bwd_fused_ws_floats(int64_t B, int32_t H, int32_t dp) {
-    return B <= 0 ? 0 : (size_t)B * (size_t)H * dp;
+    // one partial row per graph, then one per kDbiasStageRows graphs
+    return B <= 0 ? 0 : (size_t)(B + (B + kDbiasStageRows - 1) / kDbiasStageRows) * (size_t)H * dp;
 }
 
 extern "C" int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32_t dp,
@@ -1634,7 +1645,16 @@ extern "C" int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32
 #undef X
     if (dbias) {
         const int hd = H * dp;
-        hipLaunchKernelGGL(graph_dbias_sum_kernel, dim3((hd + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, ws, (int)B, hd, dbias);
+        const float *rows = ws;
+        int n_rows = (int)B;
+        if (B > 4 * kDbiasStageRows) {
+            n_rows = (int)((B + kDbiasStageRows - 1) / kDbiasStageRows);
+            float *stage = ws + (size_t)B * hd;
+            hipLaunchKernelGGL(graph_dbias_stage_kernel, dim3((hd + kSumCols - 1) / kSumCols, n_rows), dim3(kSumCols, kSumRows), 0, st, ws, (int)B, hd, stage);
+            GATMI_LAUNCH_CHECK("dense_attn_bwd_fused dbias stage");
+            rows = stage;
+        }
+        hipLaunchKernelGGL(graph_dbias_sum_kernel, dim3((hd + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, rows, n_rows, hd, dbias);
         GATMI_LAUNCH_CHECK("dense_attn_bwd_fused dbias");
     }
     return GATMI_OK;
