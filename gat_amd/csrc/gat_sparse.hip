@@ -393,7 +393,6 @@ template <int G, int LPH, int U, bool DROP, bool BF16>
 __device__ __forceinline__ void bwd_batch(SrcState &st, const BwdCscArgs &a, const int32_t *rp, int64_t cpos,
                                           float f2v, float4 whj, int sub, int head) {
     constexpr int H = G / LPH;
-    constexpr int HD = 4 * G;
     int32_t i[U];
     float4 gv[U];
     float f1v[U], lsev[U], cv[U];
