@@ -535,24 +535,37 @@ __global__ __launch_bounds__(256, 3) void xt_gemm_lines_kernel(const float *X, i
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
     const int64_t wave_stride = (int64_t)gridDim.x * 4 * kNodeChunk;
-    for (int64_t base = wave_id * kNodeChunk; base < n; base += wave_stride) {
-#pragma unroll 2
-        for (int s = 0; s < kNodeChunk / 4; ++s) {
-            const int64_t node = base + 4 * s + kq;
-            const bool nok = node < n;
-            f32x4 xa[FS];
+    // software pipeline: the rows of step t + 1 are requested before the matrix instructions of step t issue, so a
+    // wave covers its own load latency (three waves per SIMD alone left the matrix pipe idle 45 % of the time)
+    auto load_step = [&](int64_t node, f32x4 (&xa)[FS], f32x4 &yb) {
+        const bool nok = node < n;
 #pragma unroll
-            for (int fs = 0; fs < FS; ++fs)
-                xa[fs] = (nok && fok[fs]) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(X + node * ldx + f0 + 64 * fs + 4 * m)) : zero;
-            const f32x4 yb = (nok && yok) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(dY + node * hd + y0 + 4 * m)) : zero;
+        for (int fs = 0; fs < FS; ++fs)
+            xa[fs] = (nok && fok[fs]) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(X + node * ldx + f0 + 64 * fs + 4 * m)) : zero;
+        yb = (nok && yok) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(dY + node * hd + y0 + 4 * m)) : zero;
+    };
+    int64_t base = wave_id * kNodeChunk;
+    int s = 0;
+    f32x4 xa[FS], yb;
+    if (base < n) load_step(base + kq, xa, yb);
+    while (base < n) {
+        int64_t base2 = base;
+        int s2 = s + 1;
+        if (s2 == kNodeChunk / 4) { s2 = 0; base2 += wave_stride; }
+        f32x4 xn[FS], yn;
+        if (base2 < n) load_step(base2 + 4 * s2 + kq, xn, yn);
 #pragma unroll
-            for (int fs = 0; fs < FS; ++fs)
+        for (int fs = 0; fs < FS; ++fs)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        acc[fs][j][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[fs][j], yb[c], acc[fs][j][c], 0, 0, 0);
-        }
+                for (int c = 0; c < 4; ++c)
+                    acc[fs][j][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[fs][j], yb[c], acc[fs][j][c], 0, 0, 0);
+#pragma unroll
+        for (int fs = 0; fs < FS; ++fs) xa[fs] = xn[fs];
+        yb = yn;
+        base = base2;
+        s = s2;
     }
     // fixed-order sum of the four waves; red[feature_local][column_local]
     for (int w = 0; w < 4; ++w) {
