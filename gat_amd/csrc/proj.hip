@@ -274,36 +274,44 @@ __global__ __launch_bounds__(64 * kResWaves) void proj_resident_kernel(GemmArgs 
     const int col = 4 * c4;
     float4 a1v = make_float4(0.f, 0.f, 0.f, 0.f), a2v = a1v, bv = a1v;
     int head = 0;
+    float b1h = 0.f, b2h = 0.f;          // read once: a load inside the tile loop would make it wait for the prefetched tile
     if (col < g.Nc) {
         if (g.f1) {
             a1v = *reinterpret_cast<const float4 *>(g.a1 + col);
             a2v = *reinterpret_cast<const float4 *>(g.a2 + col);
             head = c4 / g.LPH;
+            b1h = g.b1[head];
+            b2h = g.b2[head];
         }
         if (g.cbias) bv = *reinterpret_cast<const float4 *>(g.cbias + col);
     }
     const int64_t tw = (int64_t)gridDim.x * kResWaves;
     int64_t tile = (int64_t)blockIdx.x * kResWaves + wave;
 
+    // The loads of the next tile are unconditional (rows past the end read the last row, k past K reads k = 0, and
+    // the values are replaced by zeros when used): a load under a branch makes the compiler wait for ALL outstanding
+    // loads before the matrix instructions, the prefetched ones included.
     float4 cur[NS], nxt[NS];
     auto load_tile = [&](int64_t t, float4 (&dst)[NS]) {
-        const int64_t row = t * 16 + m;
-        const bool ok = t < n_tiles && row < g.n;
+        const int64_t row = t * 16 + m < g.n ? t * 16 + m : g.n - 1;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int k = 16 * s + 4 * kq;
-            dst[s] = (ok && k < g.K) ? *reinterpret_cast<const float4 *>(g.A + row * g.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dst[s] = *reinterpret_cast<const float4 *>(g.A + row * g.lda + (k < g.K ? k : 0));
         }
     };
     load_tile(tile, cur);
     for (; tile < n_tiles; tile += tw) {
         load_tile(tile + tw, nxt);
+        __builtin_amdgcn_sched_barrier(0);          // the requests go out before the matrix instructions, not after
+        const bool rok = tile * 16 + m < g.n;
         f32x4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const float av[4] = {cur[s].x, cur[s].y, cur[s].z, cur[s].w};
+            const bool ok = rok && 16 * s + 4 * kq < g.K;
+            const float av[4] = {ok ? cur[s].x : 0.f, ok ? cur[s].y : 0.f, ok ? cur[s].z : 0.f, ok ? cur[s].w : 0.f};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float *brow = Ws + (16 * s + 4 * kq + t) * kLdB + m;
@@ -331,9 +339,9 @@ __global__ __launch_bounds__(64 * kResWaves) void proj_resident_kernel(GemmArgs 
                     p2 += __shfl_xor(p2, o, 64);
                 }
                 if (row < g.n && col < g.Nc && (c4 % g.LPH) == 0) {
-                    g.f1[row * g.H + head] = p1 + g.b1[head];
-                    g.f2[row * g.H + head] = p2 + g.b2[head];
-                    if (g.C16) reinterpret_cast<float *>(g.C16)[row * g.ldc16 + g.Nc / 2 + head] = p2 + g.b2[head];
+                    g.f1[row * g.H + head] = p1 + b1h;
+                    g.f2[row * g.H + head] = p2 + b2h;
+                    if (g.C16) reinterpret_cast<float *>(g.C16)[row * g.ldc16 + g.Nc / 2 + head] = p2 + b2h;
                 }
             }
             if (row < g.n && col < g.Nc) {
@@ -514,7 +522,7 @@ __global__ __launch_bounds__(256) void xt_gemm_kernel(const float *X, int64_t n,
 // Block (bx, by, bz): node chunks bx, bx+gridDim.x, ...; features [128*by, +64*FS); columns [64*bz, +64).
 // ------------------------------------------------------------------------------------------
 template <int FS>
-__global__ __launch_bounds__(256, 3) void xt_gemm_lines_kernel(const float *X, int64_t n, int F, int64_t ldx,
+__global__ __launch_bounds__(256, FS == 1 ? 3 : 2) void xt_gemm_lines_kernel(const float *X, int64_t n, int F, int64_t ldx,
                                                              const float *dY, int hd, float *ws) {
     __shared__ float red[64 * FS * 65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -533,39 +541,50 @@ __global__ __launch_bounds__(256, 3) void xt_gemm_lines_kernel(const float *X, i
     for (int fs = 0; fs < FS; ++fs) fok[fs] = f0 + 64 * fs + 4 * m < F;      // F % 4 == 0: a float4 is all in or all out
     const bool yok = y0 + 4 * m < hd;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t wave_stride = (int64_t)gridDim.x * 4 * kNodeChunk;
-    // software pipeline: the rows of step t + 1 are requested before the matrix instructions of step t issue, so a
-    // wave covers its own load latency (three waves per SIMD alone left the matrix pipe idle 45 % of the time)
-    auto load_step = [&](int64_t node, f32x4 (&xa)[FS], f32x4 &yb) {
-        const bool nok = node < n;
+    // Every wave owns one contiguous run of rows (a multiple of four long) and walks it four rows a step.
+    // Software pipeline: the rows of step t + 1 are requested before the matrix instructions of step t issue, so a
+    // wave covers its own load latency.  The loads are unconditional (lanes past the run read its last row, lanes
+    // past the width read column 0, and their values are replaced by zeros when used): a load under a branch
+    // makes the compiler wait for ALL outstanding loads before the matrix instructions, the prefetched ones included.
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int64_t per_wave = ((n + n_waves - 1) / n_waves + 3) & ~(int64_t)3;
+    const int64_t start = ((int64_t)blockIdx.x * 4 + wave) * per_wave;
+    const int rem = (int)(start < n ? (n - start < per_wave ? n - start : per_wave) : 0);      // rows of this wave
+    const unsigned ldx_bytes = (unsigned)(ldx * sizeof(float)), ldy_bytes = (unsigned)(hd * sizeof(float));
+    const char *xb[FS];
+#pragma unroll
+    for (int fs = 0; fs < FS; ++fs) xb[fs] = reinterpret_cast<const char *>(X + start * ldx + (fok[fs] ? f0 + 64 * fs + 4 * m : 0));
+    const char *yb0 = reinterpret_cast<const char *>(dY + start * hd + (yok ? y0 + 4 * m : 0));
+    auto load_step = [&](int r, f32x4 (&xa)[FS], f32x4 &yb) {
+        const unsigned rr = (unsigned)(r < rem ? r : rem - 1);
 #pragma unroll
         for (int fs = 0; fs < FS; ++fs)
-            xa[fs] = (nok && fok[fs]) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(X + node * ldx + f0 + 64 * fs + 4 * m)) : zero;
-        yb = (nok && yok) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(dY + node * hd + y0 + 4 * m)) : zero;
+            xa[fs] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xb[fs] + (uint64_t)rr * ldx_bytes));
+        yb = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(yb0 + (uint64_t)rr * ldy_bytes));
     };
-    int64_t base = wave_id * kNodeChunk;
-    int s = 0;
-    f32x4 xa[FS], yb;
-    if (base < n) load_step(base + kq, xa, yb);
-    while (base < n) {
-        int64_t base2 = base;
-        int s2 = s + 1;
-        if (s2 == kNodeChunk / 4) { s2 = 0; base2 += wave_stride; }
-        f32x4 xn[FS], yn;
-        if (base2 < n) load_step(base2 + 4 * s2 + kq, xn, yn);
+    constexpr int D = 2;                   // steps in flight behind the one being multiplied
+    f32x4 xq[D][FS], yq[D];
+    if (rem > 0) {
 #pragma unroll
-        for (int fs = 0; fs < FS; ++fs)
+        for (int d = 0; d < D; ++d) load_step(kq + 4 * d, xq[d], yq[d]);
+    }
+    for (int r = kq; r - kq < rem; r += 4 * D) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int d = 0; d < D; ++d) {
+            const bool nok = r + 4 * d < rem;      // a group's later steps may lie past the run: they multiply zeros
+            f32x4 xa[FS], yb;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    acc[fs][j][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[fs][j], yb[c], acc[fs][j][c], 0, 0, 0);
+            for (int fs = 0; fs < FS; ++fs) xa[fs] = (nok && fok[fs]) ? xq[d][fs] : zero;
+            yb = (nok && yok) ? yq[d] : zero;
+            load_step(r + 4 * (d + D), xq[d], yq[d]);          // past the end: the last row again, never used
 #pragma unroll
-        for (int fs = 0; fs < FS; ++fs) xa[fs] = xn[fs];
-        yb = yn;
-        base = base2;
-        s = s2;
+            for (int fs = 0; fs < FS; ++fs)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[fs][j][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[fs][j], yb[c], acc[fs][j][c], 0, 0, 0);
+        }
     }
     // fixed-order sum of the four waves; red[feature_local][column_local]
     for (int w = 0; w < 4; ++w) {
