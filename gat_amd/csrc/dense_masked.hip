@@ -402,14 +402,21 @@ struct MaskRow {
 
 __device__ __forceinline__ void load_mask_row(MaskRow &m, const float *bm, int N, int sub) {
 #pragma unroll
-    for (int k = 0; k < kGraphK; ++k) {
-        m.v[k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        if (64 * k < N) {                                // uniform
-            const int col = 64 * k + 4 * sub;
-            const float4 t = *reinterpret_cast<const float4 *>(bm + min(col, N - 4));      // N % 4 == 0: in bounds
-            if (col < N) m.v[k] = t;
-        }
-    }
+    // Every load is issued whatever N is (columns past the row read its last four, which the caches hold, and are
+    // replaced by -inf): with a load under a branch the compiler can no longer count what is in flight, and the
+    // next wait for anything becomes a wait for these rows, which are meant to travel during the current rows' work.
+    // The replacement happens where the row is used (mask_row_trim), not here: a select right behind the load
+    // lets the compiler put the load back under a branch.
+    for (int k = 0; k < kGraphK; ++k)
+        m.v[k] = *reinterpret_cast<const float4 *>(bm + min(64 * k + 4 * sub, N - 4));      // N % 4 == 0: in bounds
+}
+
+// the columns past the row's end become -inf (coefficient exactly 0, never listed)
+__device__ __forceinline__ MaskRow mask_row_trim(const MaskRow &m, int N, int sub) {
+    MaskRow r;
+#pragma unroll
+    for (int k = 0; k < kGraphK; ++k) r.v[k] = 64 * k + 4 * sub < N ? m.v[k] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    return r;
 }
 
 // maximum / sum over the 16 lanes of a DPP row, in every lane of the row
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(kGraphFwdThreads) void dense_graph_fwd_kernel(Maske
     const float *whl = whs + sub * 4;
     const float *f2l = f2s + head;
     for (; row0 < N; row0 += nwaves * RPW) {
-        const MaskRow cur = next;
+        const MaskRow cur = mask_row_trim(next, N, sub);
         if (row0 + nwaves * RPW < N)                     // the next rows travel during this quad's work
             load_mask_row(next, bmat + min(row0 + nwaves * RPW + grp, N - 1) * N, N, sub);
         const int i = min(row0 + grp, N - 1);
@@ -659,7 +666,7 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_fwd8_kernel(
     // quads of this wave in order: (oct0, first half), (oct0, second half), (oct0 + nwaves * 8, first half), ...
     MaskRow next;
     int oct0 = wave * kGraphWalkRows;
-    if (oct0 < N) load_mask_row(next, bmat + min(oct0 + grp, N - 1) * N, N, sub);
+    load_mask_row(next, bmat + min(oct0 + grp, N - 1) * N, N, sub);
     {
         const float4 *src = reinterpret_cast<const float4 *>(a.Wh + b * N * (int64_t)HD);
         for (int e = threadIdx.x; e < NP * (HD / 4); e += blockDim.x)
@@ -680,10 +687,10 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_fwd8_kernel(
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int row0 = oct0 + 4 * half;
-            const MaskRow cur = next;
+            const MaskRow cur = mask_row_trim(next, N, sub);
             {                                                // the next quad's rows travel during this quad's work
                 const int nrow0 = half == 0 ? row0 + 4 : oct0 + nwaves * kGraphWalkRows;
-                if (nrow0 < N) load_mask_row(next, bmat + min(nrow0 + grp, N - 1) * N, N, sub);
+                load_mask_row(next, bmat + min(nrow0 + grp, N - 1) * N, N, sub);      // past the graph: its last row again, never used
             }
             uint16_t *lrow = lists + (4 * half + grp) * lc;
             if (row0 >= N) {                                 // wave-uniform: an octet's second quad beyond the graph
