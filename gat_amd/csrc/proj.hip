@@ -940,7 +940,8 @@ extern "C" int gatmi_proj_bwd_params(const float *X, int64_t n, int32_t f_in, in
 #undef X_
         if (rc) return rc;
     }
-    if (ldx % 4 == 0 && f_in % 4 == 0 && aligned16(X) && aligned16(dWh) && f_in <= 1024)
+    // (the kernel forms row offsets as 32-bit row x 32-bit row stride in bytes)
+    if (ldx % 4 == 0 && f_in % 4 == 0 && aligned16(X) && aligned16(dWh) && f_in <= 1024 && ldx < ((int64_t)1 << 29))
         return launch_xt_lines(X, n, f_in, ldx, dWh, hd, ws, dW, st);
     // rows of X that are not 16-byte aligned: dW in column slabs of 64 (one slab for hd <= 64); the
     // slabs share the workspace, which the stream order makes safe
