@@ -1207,10 +1207,13 @@ __device__ __forceinline__ void graph_bwd_batch8(MSrcState8 &st, float slope, co
 }
 
 // LDS: g [N + pad][64] | stats [N + pad][3H] | bits [N][W] | lists [waves][8][lc] (uint16) | entry counts [waves][8] (int)
+// The fused kernel first sums the bias gradient over the block through the list area (one float4 per thread): small
+// graphs have lists shorter than that, so the area is at least that large.
 static inline size_t graph8_bwd_lds(int N, int H, int lc, int waves) {
     const int W = (N + 31) / 32 + 1;
-    return (size_t)(N + kGraphPadRows) * (64 + 3 * H) * sizeof(float) + (size_t)N * W * sizeof(uint32_t) +
-           (size_t)waves * kGraphWalkRows * lc * sizeof(uint16_t) + (size_t)waves * kGraphWalkRows * sizeof(int);
+    const size_t lists = (size_t)waves * kGraphWalkRows * lc * sizeof(uint16_t) + (size_t)waves * kGraphWalkRows * sizeof(int);
+    const size_t block_sum = (size_t)waves * 64 * sizeof(float4);
+    return (size_t)(N + kGraphPadRows) * (64 + 3 * H) * sizeof(float) + (size_t)N * W * sizeof(uint32_t) + std::max(lists, block_sum);
 }
 
 template <int LPH8, bool FUSED>

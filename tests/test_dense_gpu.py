@@ -336,8 +336,9 @@ def test_graph_resident_kernels_for_batches_of_many_small_graphs(B, N, F, H, D, 
                                   ops.make_cfg(H, D, "elu", mask_path=path))
         out.backward(torch.tensor(dout, device=dev))
         res[path] = (out.detach().cpu().numpy(), xt.grad.cpu().numpy(), tp["W"].grad.cpu().numpy(), tp["a1"].grad.cpu().numpy(),
-                     tp["a2"].grad.cpu().numpy())
-    for a, b, name in zip(res["lists"], res["dense"], ("out", "dX", "dW", "da1", "da2")):
+                     tp["a2"].grad.cpu().numpy(), tp["bias"].grad.cpu().numpy(), tp["b1"].grad.cpu().numpy(), tp["b2"].grad.cpu().numpy())
+    # the bias gradient of the graph-resident backward is summed per graph and then over the graphs in two stages
+    for a, b, name in zip(res["lists"], res["dense"], ("out", "dX", "dW", "da1", "da2", "dbias", "db1", "db2")):
         assert_close(a, b, rtol=1e-5, atol_scale=5e-6, what="graph-resident vs matrix cores " + name)
     for sl in (slice(0, 3), slice(B - 2, B)):
         rp = {k: torch.tensor(v, dtype=torch.float64) for k, v in p.items()}
@@ -346,3 +347,34 @@ def test_graph_resident_kernels_for_batches_of_many_small_graphs(B, N, F, H, D, 
         ref.backward(torch.tensor(dout[sl].astype(np.float64)))
         assert_close(res["lists"][0][sl], ref.detach().numpy(), what="graph-resident forward vs oracle")
         assert_close(res["lists"][1][sl], rx.grad.numpy(), atol_scale=5e-6, what="graph-resident dX vs oracle")
+
+
+@pytest.mark.parametrize("B,N,F,H,D", [(256, 52, 6, 8, 8), (270, 100, 9, 4, 16)])
+def test_graph_resident_kernels_with_a_residual_projection(B, N, F, H, D):
+    """The residual branch (utils/layers.py:28-32, widths differ: a second projection with bias) through the
+    graph-resident list kernels: the activation's derivative then comes from the saved output and g is written
+    for dW_res.  Every gradient against the matrix-core kernels, two graphs against the float64 oracle."""
+    from gat_amd import ops
+    dev = torch.device("cuda:0")
+    bm = _masks(B, N, 0.1, 90 + N).astype(np.float32)
+    p = layer_params(F, H, D, seed=N + 3, res=True)
+    x = np.random.default_rng(N + 4).normal(0, 1, (B, N, F)).astype(np.float32)
+    dout = np.random.default_rng(N + 5).normal(0, 1, (B, N, H * D)).astype(np.float32)
+    names = ("W", "a1", "a2", "b1", "b2", "bias", "W_res", "b_res")
+    res = {}
+    for path in ("lists", "dense"):
+        tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+        xt = torch.tensor(x, device=dev, requires_grad=True)
+        out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], torch.tensor(bm, device=dev),
+                                  ops.make_cfg(H, D, "elu", mask_path=path), tp["W_res"], tp["b_res"])
+        out.backward(torch.tensor(dout, device=dev))
+        res[path] = [out.detach().cpu().numpy(), xt.grad.cpu().numpy()] + [tp[k].grad.cpu().numpy() for k in names]
+    for a, b, name in zip(res["lists"], res["dense"], ("out", "dX") + tuple("d" + k for k in names)):
+        assert_close(a, b, rtol=1e-5, atol_scale=5e-6, what="graph-resident vs matrix cores, residual: " + name)
+    sl = slice(B - 2, B)
+    rp = {k: torch.tensor(v, dtype=torch.float64) for k, v in p.items()}
+    rx = torch.tensor(x[sl].astype(np.float64), requires_grad=True)
+    ref = ref_torch.layer_dense(rx, rp, torch.tensor(bm[sl].astype(np.float64)), "elu", "concat", residual=True)
+    ref.backward(torch.tensor(dout[sl].astype(np.float64)))
+    assert_close(res["lists"][0][sl], ref.detach().numpy(), what="graph-resident forward vs oracle, residual")
+    assert_close(res["lists"][1][sl], rx.grad.numpy(), atol_scale=5e-6, what="graph-resident dX vs oracle, residual")
