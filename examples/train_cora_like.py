@@ -7,6 +7,12 @@ l2 0.0005, dropout 0.6/0.6, ELU, early stopping with patience 100 on (val acc up
 graph with Cora's shape (2708 nodes, 1433 sparse binary features, 7 classes).
 
     python examples/train_cora_like.py --epochs 200
+    python examples/train_cora_like.py --epochs 200 --replay     # both steps replayed from HIP graphs
+
+--replay captures the training step (forward with dropout, loss, backward, Adam) and the evaluation
+step once and replays them: an eager step at this size is bound by the host issuing ~60 launches of
+a few microseconds.  The in-kernel dropout masks change on every replay (gat_amd.graphs.capture keeps
+a step word on the device for them) and Adam keeps its step count on the device (capturable).
 """
 import argparse
 import os
@@ -57,8 +63,9 @@ def main():
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--sparse-features", action="store_true",
                     help="feed the sparse tuple of preprocess_features (stored entries only) instead of the dense matrix")
+    ap.add_argument("--replay", action="store_true", help="capture the training and evaluation steps into HIP graphs and replay them")
     args = ap.parse_args()
-    from gat_amd import CSRGraph, layers, preprocess
+    from gat_amd import CSRGraph, graphs, layers, preprocess
     from gat_amd.models import SpGAT
 
     dev = torch.device("cuda:0")
@@ -85,21 +92,43 @@ def main():
             return SpGAT.inference(x, 7, n, train, drop, drop, bias_mat=graph, **kw)[0]
 
     forward(False)                                                         # creates the variables
-    opt, l2 = SpGAT.training(store.parameters(), lr=0.005, l2_coef=0.0005)
-    best_acc, best_loss, wait, best_state = 0.0, float("inf"), 0, None
-    t0 = time.time()
-    for epoch in range(args.epochs):
+    opt, l2 = SpGAT.training(store.parameters(), lr=0.005, l2_coef=0.0005, capturable=args.replay)
+    stats = torch.zeros(3, device=dev)                                     # train loss, val loss, val acc
+
+    def train_step():
         opt.zero_grad(set_to_none=True)
         logits = forward(True)
         loss = SpGAT.masked_softmax_cross_entropy(logits, y, masks["train"]) + l2()
         loss.backward()
         opt.step()
+        stats[0].copy_(loss.detach())
+
+    def eval_step():
         with torch.no_grad():
             logits = forward(False)
-            vl = SpGAT.masked_softmax_cross_entropy(logits, y, masks["val"]).item()
-            va = SpGAT.masked_accuracy(logits, y, masks["val"]).item()
+            stats[1].copy_(SpGAT.masked_softmax_cross_entropy(logits, y, masks["val"]))
+            stats[2].copy_(SpGAT.masked_accuracy(logits, y, masks["val"]))
+
+    if args.replay:
+        # the warm-up calls of the capture are real training steps: start the count from them
+        state0 = {k: v.detach().clone() for k, v in store.state_dict().items()}
+        train_step, _ = graphs.capture(train_step, warmup=2)
+        eval_step, _ = graphs.capture(eval_step, warmup=1)
+        store.load_state_dict(state0)
+        for st in opt.state.values():
+            st["m"].zero_()
+            st["v"].zero_()
+        for group in opt.param_groups:
+            group["t_dev"].zero_()
+    best_acc, best_loss, wait, best_state = 0.0, float("inf"), 0, None
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for epoch in range(args.epochs):
+        train_step()
+        eval_step()
+        tl, vl, va = stats.tolist()
         if not args.quiet and epoch % 10 == 0:
-            print("epoch %4d  train loss %.4f | val loss %.4f acc %.4f" % (epoch, loss.item(), vl, va))
+            print("epoch %4d  train loss %.4f | val loss %.4f acc %.4f" % (epoch, tl, vl, va))
         if va >= best_acc or vl <= best_loss:                              # execute_cora_sparse.py:146-156
             if va >= best_acc and vl <= best_loss:
                 best_state = {k: v.detach().clone() for k, v in store.state_dict().items()}

@@ -51,6 +51,8 @@ _SIGNATURES = {
                               c_float, c_float, c_float, c_uint64, P, P, P, P, P, P, P]),
     "gatmi_gat_fwd_noalloc": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, c_int64, P, P, c_int32, c_int64, P, P, P, P, P, P,
                                       c_int32, c_int32, c_float, c_float, c_float, c_uint64, P, P, P, P, P, P]),
+    "gatmi_dropout_step_source": (c_int, [P]),
+    "gatmi_dropout_step_multiplier": (c_uint64, []),
     "gatmi_gat_bwd_node_ws_floats": (c_size_t, [c_int32, c_int32]),
     "gatmi_gat_bwd_node": (c_int, [c_int64, c_int32, c_int32, P, P, P, P, P, P, P, P, c_int32, c_int32, c_float,
                                    P, c_int64, P, c_int64, P, c_int64, P, P, P, P]),

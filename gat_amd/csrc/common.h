@@ -12,6 +12,10 @@ namespace gatmi {
 char *error_buffer();
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// The device word registered for the current device with gatmi_dropout_step_source, or nullptr.
+// Entry points with dropout switched on hand it to their kernels (device_common.h: seed_now).
+const uint64_t *dropout_step_source();
+
 inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // (H, dp) -> lanes per row G = H*dp/4 and lanes per head LPH = dp/4; both powers of two.

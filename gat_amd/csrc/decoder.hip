@@ -25,6 +25,7 @@ struct IpdArgs {
     float *out, *dZ;
     float keep;
     uint64_t seed;
+    const uint64_t *seed_step;   // device word added to the seed at run time (seed_now), or nullptr
     int activation;
 };
 
@@ -38,7 +39,7 @@ struct IpdShape {
 
 __device__ __forceinline__ float ipd_load(const IpdArgs &a, int64_t row, int c) {
     float v = a.Z[row * a.F + c];
-    if (a.keep < 1.f) v = drop_feat1(v, a.seed, row, a.F, c, a.keep);
+    if (a.keep < 1.f) v = drop_feat1(v, seed_now(a), row, a.F, c, a.keep);
     return v;
 }
 
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void ipd_bwd_kernel(IpdArgs a) {
             const int c = 16 * nt + m;
             if (c < a.F) {
                 float v = acc[nt][r];
-                if (a.keep < 1.f) v = drop_feat1(v, a.seed, b * N + i, a.F, c, a.keep);
+                if (a.keep < 1.f) v = drop_feat1(v, seed_now(a), b * N + i, a.F, c, a.keep);
                 a.dZ[(b * N + i) * (int64_t)a.F + c] = v;
             }
         }
@@ -173,7 +174,7 @@ __device__ __forceinline__ void ipd_stage_graph(const IpdArgs &a, int64_t b, int
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < a.N && c < a.F) {
                 v = *reinterpret_cast<const float4 *>(a.Z + (b * a.N + r) * (int64_t)a.F + c);
-                if (a.keep < 1.f) v = drop_feat(v, a.seed, b * a.N + r, a.F, c, a.keep);
+                if (a.keep < 1.f) v = drop_feat(v, seed_now(a), b * a.N + r, a.F, c, a.keep);
             }
             *reinterpret_cast<float4 *>(zs + r * S::LD + c) = v;
         }
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(64 * kGraphWaves) void ipd_bwd_graph_kernel(IpdArgs
                 const int c = 16 * nt_ + m;
                 if (c < a.F) {
                     float v = acc[nt_][r];
-                    if (a.keep < 1.f) v = drop_feat1(v, a.seed, b * N + i, a.F, c, a.keep);
+                    if (a.keep < 1.f) v = drop_feat1(v, seed_now(a), b * N + i, a.F, c, a.keep);
                     a.dZ[(b * N + i) * (int64_t)a.F + c] = v;
                 }
             }
@@ -362,7 +363,7 @@ extern "C" int gatmi_ipd_fwd(int64_t B, int32_t N, int32_t F, const float *Z, in
     if (B == 0 || N == 0) return GATMI_OK;
     GATMI_REQUIRE(Z && out, GATMI_EINVAL, "ipd_fwd: null pointer");
     IpdArgs a = {};
-    a.N = N; a.F = F; a.Z = Z; a.out = out; a.keep = keep; a.seed = seed; a.activation = activation;
+    a.N = N; a.F = F; a.Z = Z; a.out = out; a.keep = keep; a.seed = seed; a.seed_step = keep < 1.f ? dropout_step_source() : nullptr; a.activation = activation;
     GATMI_IPD_LAUNCH(ipd_fwd_kernel, ipd_fwd_graph_kernel, "ipd_fwd");
     return GATMI_OK;
 }
@@ -376,7 +377,7 @@ extern "C" int gatmi_ipd_bwd(int64_t B, int32_t N, int32_t F, const float *dOut,
     GATMI_REQUIRE(activation != GATMI_ACT_SIGMOID || out, GATMI_EINVAL, "ipd_bwd: the sigmoid needs the saved output");
     IpdArgs a = {};
     a.N = N; a.F = F; a.Z = Z; a.dOut = dOut; a.out_saved = activation == GATMI_ACT_SIGMOID ? out : nullptr;
-    a.dZ = dZ; a.keep = keep; a.seed = seed; a.activation = activation;
+    a.dZ = dZ; a.keep = keep; a.seed = seed; a.seed_step = keep < 1.f ? dropout_step_source() : nullptr; a.activation = activation;
     GATMI_IPD_LAUNCH(ipd_bwd_kernel, ipd_bwd_graph_kernel, "ipd_bwd");
     return GATMI_OK;
 }

@@ -36,6 +36,7 @@ struct DenseFwdArgs {
     int activation;
     float slope, coef_keep, feat_keep;
     uint64_t seed;
+    const uint64_t *seed_step;   // device word added to the seed at run time (seed_now), or nullptr
 };
 
 // How the four waves of a block split the work: heads first (each wave keeps only HPW heads'
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_kernel(DenseFwdArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (jc + r < N) v = *reinterpret_cast<const float4 *>(a.Wh + (b * N + jc + r) * (int64_t)HD + 4 * c);
             if constexpr (DROP) {
-                if (a.feat_keep < 1.f) v = drop_feat(v, a.seed, b * N + jc + r, HD, 4 * c, a.feat_keep);
+                if (a.feat_keep < 1.f) v = drop_feat(v, seed_now(a), b * N + jc + r, HD, 4 * c, a.feat_keep);
             }
             *reinterpret_cast<float4 *>(vs + r * LD + 4 * c) = v;
         }
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_kernel(DenseFwdArgs a) {
                     if constexpr (DROP) {
                         ssum[h] += p0;
                         qsum[h] += z > 0.f ? p0 : 0.f;
-                        if (a.coef_keep < 1.f) p = p0 * coef_drop_scale(a.seed, b, N, H, irow, min(jc + jl + 4 * kq + t, N - 1), h0 + h, a.coef_keep);
+                        if (a.coef_keep < 1.f) p = p0 * coef_drop_scale(seed_now(a), b, N, H, irow, min(jc + jl + 4 * kq + t, N - 1), h0 + h, a.coef_keep);
                     }
                     const float pp = z > 0.f ? p : 0.f;
 #pragma unroll
@@ -219,6 +220,7 @@ struct DenseBwdArgs {
     float *dWh, *df2;
     float slope, coef_keep, feat_keep;
     uint64_t seed;
+    const uint64_t *seed_step;   // device word added to the seed at run time (seed_now), or nullptr
 };
 
 // Block (b, source tiles): a wave owns 16 sources x HPW heads and walks all destination tiles.
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_kernel(DenseBwdArgs a) {
         for (int s = 0; s < KS; ++s) {
             whb[h][s] = a.Wh[(b * N + jcol) * (int64_t)HD + (h0 + h) * DP + 4 * s + kq];
             if constexpr (DROP) {
-                if (a.feat_keep < 1.f) whb[h][s] = drop_feat1(whb[h][s], a.seed, b * N + jcol, HD, (h0 + h) * DP + 4 * s + kq, a.feat_keep);
+                if (a.feat_keep < 1.f) whb[h][s] = drop_feat1(whb[h][s], seed_now(a), b * N + jcol, HD, (h0 + h) * DP + 4 * s + kq, a.feat_keep);
             }
         }
 #pragma unroll
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_kernel(DenseBwdArgs a) {
                     const float alpha = exp_neg(leaky(z, a.slope) + bv[r] - st[H + hg]);   // 0 outside the graph
                     float mk = 1.f;
                     if constexpr (DROP) {
-                        if (a.coef_keep < 1.f) mk = coef_drop_scale(a.seed, b, N, H, min(ic + il + 4 * kq + r, N - 1), jcol, hg, a.coef_keep);
+                        if (a.coef_keep < 1.f) mk = coef_drop_scale(seed_now(a), b, N, H, min(ic + il + 4 * kq + r, N - 1), jcol, hg, a.coef_keep);
                     }
                     al[r] = alpha * mk;
                     df2[h] += alpha * (da[r] * mk - st[2 * H + hg]) * (z > 0.f ? 1.f : a.slope);
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_kernel(DenseBwdArgs a) {
                 if (c < DP) {
                     float v = acc[h][nt][r];
                     if constexpr (DROP) {
-                        if (a.feat_keep < 1.f) v = drop_feat1(v, a.seed, b * N + j, HD, hg * DP + c, a.feat_keep);
+                        if (a.feat_keep < 1.f) v = drop_feat1(v, seed_now(a), b * N + j, HD, hg * DP + c, a.feat_keep);
                     }
                     if (a.a1) v += d1 * a.a1[hg * DP + c] + d2 * a.a2[hg * DP + c];
                     a.dWh[(b * N + j) * (int64_t)HD + hg * DP + c] = v;
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_hg_kernel(DenseFwdArgs a) 
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < N) v = *reinterpret_cast<const float4 *>(a.Wh + (b * N + r) * (int64_t)HD + h0 * DP + 4 * c);
         if constexpr (DROP) {
-            if (a.feat_keep < 1.f) v = drop_feat(v, a.seed, b * N + r, HD, h0 * DP + 4 * c, a.feat_keep);
+            if (a.feat_keep < 1.f) v = drop_feat(v, seed_now(a), b * N + r, HD, h0 * DP + 4 * c, a.feat_keep);
         }
         *reinterpret_cast<float4 *>(vs + r * LDV + 4 * c) = v;
     }
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(256) void dense_attn_fwd_hg_kernel(DenseFwdArgs a) 
                     if constexpr (DROP) {
                         ssum[h] += p0;
                         qsum[h] += z > 0.f ? p0 : 0.f;
-                        if (a.coef_keep < 1.f) p = p0 * coef_drop_scale(a.seed, b, N, H, irow, min(j0 + 4 * kq + t, N - 1), h0 + h, a.coef_keep);
+                        if (a.coef_keep < 1.f) p = p0 * coef_drop_scale(seed_now(a), b, N, H, irow, min(j0 + 4 * kq + t, N - 1), h0 + h, a.coef_keep);
                     }
                     const float pp = z > 0.f ? p : 0.f;
 #pragma unroll
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_hg_kernel(DenseBwdArgs a) 
             for (int s = 0; s < KS; ++s) {
             whb[h][s] = a.Wh[(b * N + jcol) * (int64_t)HD + (h0 + h) * DP + 4 * s + kq];
             if constexpr (DROP) {
-                if (a.feat_keep < 1.f) whb[h][s] = drop_feat1(whb[h][s], a.seed, b * N + jcol, HD, (h0 + h) * DP + 4 * s + kq, a.feat_keep);
+                if (a.feat_keep < 1.f) whb[h][s] = drop_feat1(whb[h][s], seed_now(a), b * N + jcol, HD, (h0 + h) * DP + 4 * s + kq, a.feat_keep);
             }
         }
 #pragma unroll
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_hg_kernel(DenseBwdArgs a) 
                     const float alpha = exp_neg(leaky(z, a.slope) + bv[r] - st[r].y);   // 0 outside the graph
                     float mk = 1.f;
                     if constexpr (DROP) {
-                        if (a.coef_keep < 1.f) mk = coef_drop_scale(a.seed, b, N, H, min(il + 4 * kq + r, N - 1), jcol, h0 + h, a.coef_keep);
+                        if (a.coef_keep < 1.f) mk = coef_drop_scale(seed_now(a), b, N, H, min(il + 4 * kq + r, N - 1), jcol, h0 + h, a.coef_keep);
                     }
                     al[r] = alpha * mk;
                     df2[h] += alpha * (da[r] * mk - st[r].z) * (z > 0.f ? 1.f : a.slope);
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(256) void dense_attn_bwd_hg_kernel(DenseBwdArgs a) 
                     if (c < DP) {
                         float v = acc[h][nt][r];
                     if constexpr (DROP) {
-                        if (a.feat_keep < 1.f) v = drop_feat1(v, a.seed, b * N + j, HD, hg * DP + c, a.feat_keep);
+                        if (a.feat_keep < 1.f) v = drop_feat1(v, seed_now(a), b * N + j, HD, hg * DP + c, a.feat_keep);
                     }
                         if (a.a1) v += d1 * a.a1[hg * DP + c] + d2 * a.a2[hg * DP + c];
                         a.dWh[(b * N + j) * (int64_t)HD + hg * DP + c] = v;
@@ -724,7 +726,7 @@ extern "C" int gatmi_dense_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t dp,
     GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(bias_mat);
     DenseFwdArgs a;
     a.B = B; a.N = N; a.Wh = Wh; a.f1 = f1; a.f2 = f2; a.bias_mat = bias_mat; a.bias = bias; a.resid = resid;
-    a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.activation = activation; a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
+    a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.activation = activation; a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.seed_step = (coef_keep < 1.f || feat_keep < 1.f) ? dropout_step_source() : nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X(hh, dd)                                                                                             \
     if (H == hh && dp == dd) {                                                                                \
@@ -762,7 +764,7 @@ extern "C" int gatmi_dense_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t dp,
     GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "dense_attn_bwd: keep probabilities must be in (0,1]");
     const bool drop = coef_keep < 1.f || feat_keep < 1.f;
     DenseBwdArgs a;
-    a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
+    a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.seed_step = (coef_keep < 1.f || feat_keep < 1.f) ? dropout_step_source() : nullptr;
     a.df1 = df1; a.a1 = a1; a.a2 = a2;
     a.B = B; a.N = N; a.g = g; a.stats = stats; a.Wh = Wh; a.f2 = f2; a.bias_mat = bias_mat; a.dWh = dWh; a.df2 = df2; a.slope = slope;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

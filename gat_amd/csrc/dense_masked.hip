@@ -46,6 +46,7 @@ struct MaskedFwdArgs {
     int activation;
     float slope, coef_keep, feat_keep;
     uint64_t seed;
+    const uint64_t *seed_step;   // device word added to the seed at run time (seed_now), or nullptr
 };
 
 struct MRowState {
@@ -115,8 +116,8 @@ __device__ __forceinline__ void masked_fwd_batch(MRowState &st, const MaskedFwdA
         float pa = p;
         float4 vv = v[t];
         if (DROP) {
-            if (a.coef_keep < 1.f) pa = p * coef_drop_scale(a.seed, b, N, H, i, j[t], head, a.coef_keep);
-            if (a.feat_keep < 1.f) vv = drop_feat(vv, a.seed, b * N + j[t], HD, sub * 4, a.feat_keep);
+            if (a.coef_keep < 1.f) pa = p * coef_drop_scale(seed_now(a), b, N, H, i, j[t], head, a.coef_keep);
+            if (a.feat_keep < 1.f) vv = drop_feat(vv, seed_now(a), b * N + j[t], HD, sub * 4, a.feat_keep);
         }
         bacc = f4_fma(pa, vv, bacc);
         if (SAVE) {
@@ -821,6 +822,7 @@ struct MaskedBwdArgs {
     float *dWh, *df2;
     float slope, coef_keep, feat_keep;
     uint64_t seed;
+    const uint64_t *seed_step;   // device word added to the seed at run time (seed_now), or nullptr
     // fused per-destination step (dense_graph_bwd8_kernel<.., true>): g, stats and df1 are formed from these while
     // the graph is staged, instead of being read from arrays an earlier launch wrote
     const float *dout, *out, *agg, *pos, *q, *f1, *lse, *bias;
@@ -870,7 +872,7 @@ __device__ __forceinline__ void masked_bwd_batch(MSrcState &st, const MaskedBwdA
         float aa = alpha;
         if (DROP) {
             if (a.coef_keep < 1.f) {
-                const float mk = coef_drop_scale(a.seed, b, N, H, i[t], jcol, head, a.coef_keep);
+                const float mk = coef_drop_scale(seed_now(a), b, N, H, i[t], jcol, head, a.coef_keep);
                 aa = alpha * mk;
                 dalpha *= mk;
             }
@@ -916,7 +918,7 @@ __global__ __launch_bounds__(256, GATMI_MASK_MINBLOCKS) void dense_masked_bwd_ke
         f2v[p] = a.f2[(b * N + jcol) * H + head];
         whj[p] = *reinterpret_cast<const float4 *>(a.Wh + (b * N + jcol) * (int64_t)HD + sub * 4);
         if (DROP) {
-            if (a.feat_keep < 1.f) whj[p] = drop_feat(whj[p], a.seed, b * N + jcol, HD, sub * 4, a.feat_keep);
+            if (a.feat_keep < 1.f) whj[p] = drop_feat(whj[p], seed_now(a), b * N + jcol, HD, sub * 4, a.feat_keep);
         }
     }
 
@@ -991,7 +993,7 @@ __global__ __launch_bounds__(256, GATMI_MASK_MINBLOCKS) void dense_masked_bwd_ke
         const int64_t j = b * N + jcol;
         float4 r = st[p].acc;
         if (DROP) {
-            if (a.feat_keep < 1.f) r = drop_feat(r, a.seed, j, HD, sub * 4, a.feat_keep);
+            if (a.feat_keep < 1.f) r = drop_feat(r, seed_now(a), j, HD, sub * 4, a.feat_keep);
         }
         if (a.a1) {
             const float d1 = a.df1[j * H + head];
@@ -1470,7 +1472,7 @@ extern "C" int gatmi_dense_attn_fwd_masked(int64_t B, int32_t N, int32_t H, int3
     MaskedFwdArgs a;
     a.B = B; a.N = N; a.Wh = Wh; a.f1 = f1; a.f2 = f2; a.bias_mat = bias_mat; a.bias = bias; a.resid = resid;
     a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.activation = activation; a.slope = slope;
-    a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.present = present;
+    a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.seed_step = (coef_keep < 1.f || feat_keep < 1.f) ? dropout_step_source() : nullptr; a.present = present;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // many small graphs: one block per graph with the graph's rows resident in LDS
     const int lc = graph_list_capacity(N);
@@ -1546,7 +1548,7 @@ extern "C" int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int3
     const bool drop = coef_keep < 1.f || feat_keep < 1.f;
     MaskedBwdArgs a;
     a.B = B; a.N = N; a.g = g; a.stats = stats; a.Wh = Wh; a.f2 = f2; a.bias_mat = bias_mat; a.df1 = df1; a.a1 = a1; a.a2 = a2;
-    a.dWh = dWh; a.df2 = df2; a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.present = present;
+    a.dWh = dWh; a.df2 = df2; a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.seed_step = (coef_keep < 1.f || feat_keep < 1.f) ? dropout_step_source() : nullptr; a.present = present;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // many small graphs: one block per graph with the graph's rows resident in LDS
     const int lcg = graph_list_capacity(N);

@@ -99,6 +99,18 @@ __device__ __forceinline__ bool keep_mask(uint64_t seed, uint64_t idx, float kee
 
 constexpr uint64_t kFeatSeedSalt = 0x5DEECE66Dull;
 
+// Dropout under HIP-graph replay: kernel arguments are frozen at capture, so a captured step would
+// replay one set of masks for ever.  A launch may therefore carry, next to its seed, the address of a
+// 64-bit step word in device memory (gatmi_dropout_step_source); the kernel reads it when it runs and
+// uses seed + word * kSeedStepMul.  The odd multiplier keeps (seed + small head-group offset, step)
+// pairs apart.  nullptr: the seed as passed.  A uniform read-only load: the compiler issues it as a
+// scalar load once per use site.
+constexpr uint64_t kSeedStepMul = 0xD1B54A32D192ED03ull;
+template <class Args>
+__device__ __forceinline__ uint64_t seed_now(const Args &a) {
+    return a.seed_step ? a.seed + *a.seed_step * kSeedStepMul : a.seed;
+}
+
 // feature-dropout of one float4 of row j (columns c0..c0+3): utils/layers.py:22
 __device__ __forceinline__ float4 drop_feat(float4 v, uint64_t seed, int64_t j, int hd, int c0, float keep) {
     const uint64_t base = (uint64_t)j * (uint64_t)hd + (uint64_t)c0;

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 
 #include "common.h"
@@ -50,6 +51,7 @@ struct FwdArgs {
     int activation, reduce;
     float slope, coef_keep, feat_keep;
     uint64_t seed;
+    const uint64_t *seed_step;   // device word added to the seed at run time (seed_now), or nullptr
 };
 
 struct RowState {
@@ -102,8 +104,8 @@ __device__ __forceinline__ void fwd_batch(RowState &st, const FwdArgs &a, const 
         float4 vv = v[t];
         if (DROP) {
             if (a.coef_keep < 1.f)
-                pa = keep_mask(a.seed, (uint64_t)(epos + t) * H + head, a.coef_keep) ? p / a.coef_keep : 0.f;
-            if (a.feat_keep < 1.f) vv = drop_feat(vv, a.seed, j[t], HD, sub * 4, a.feat_keep);
+                pa = keep_mask(seed_now(a), (uint64_t)(epos + t) * H + head, a.coef_keep) ? p / a.coef_keep : 0.f;
+            if (a.feat_keep < 1.f) vv = drop_feat(vv, seed_now(a), j[t], HD, sub * 4, a.feat_keep);
         }
         bacc = f4_fma(pa, vv, bacc);
         if (SAVE) {
@@ -382,6 +384,7 @@ struct BwdCscArgs {
     float *dfeat, *df2, *ws;
     float slope, coef_keep, feat_keep;
     uint64_t seed;
+    const uint64_t *seed_step;   // device word added to the seed at run time (seed_now), or nullptr
 };
 
 struct SrcState {
@@ -416,7 +419,7 @@ __device__ __forceinline__ void bwd_batch(SrcState &st, const BwdCscArgs &a, con
         float aa = alpha;
         if (DROP) {
             if (a.coef_keep < 1.f) {
-                const bool kp = keep_mask(a.seed, (uint64_t)a.perm[cpos + t] * H + head, a.coef_keep);
+                const bool kp = keep_mask(seed_now(a), (uint64_t)a.perm[cpos + t] * H + head, a.coef_keep);
                 const float mk = kp ? 1.0f / a.coef_keep : 0.f;
                 aa = alpha * mk;
                 dalpha *= mk;
@@ -436,7 +439,7 @@ __device__ __forceinline__ void bwd_finish(const SrcState &st, const BwdCscArgs 
     constexpr int HD = 4 * G;
     float4 r = st.acc;
     if (DROP) {
-        if (a.feat_keep < 1.f) r = drop_feat(r, a.seed, j, HD, sub * 4, a.feat_keep);
+        if (a.feat_keep < 1.f) r = drop_feat(r, seed_now(a), j, HD, sub * 4, a.feat_keep);
     }
     if (a.a1) {
         const float d1 = a.df1[j * H + head];
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(256) void gat_bwd_csc_kernel(BwdCscArgs a) {
         f2v = group_sum<LPH>(dot4(w, *reinterpret_cast<const float4 *>(a.la2 + sub * 4))) + (a.lb2 ? a.lb2[head] : 0.f);
     }
     if (DROP) {
-        if (a.feat_keep < 1.f) whj = drop_feat(whj, a.seed, j, HD, sub * 4, a.feat_keep);
+        if (a.feat_keep < 1.f) whj = drop_feat(whj, seed_now(a), j, HD, sub * 4, a.feat_keep);
     }
     SrcState st;
     st.acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -806,7 +809,7 @@ static int gat_fwd_impl(const char *name, int64_t n_dst, int32_t H, int32_t dp,
     a.col = col; a.feat = feat; a.ldf = ldfeat; a.f1 = f1; a.f2 = f2; a.la2 = logit_a2; a.lb2 = logit_b2; a.bias = bias; a.resid = resid;
     a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.ws = ws; a.ws_slots = ws_slots;
     a.activation = activation; a.reduce = reduce;
-    a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
+    a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.seed_step = (coef_keep < 1.f || feat_keep < 1.f) ? dropout_step_source() : nullptr;
     const bool drop = coef_keep < 1.f || feat_keep < 1.f;
     const bool bf16 = feat_dtype == GATMI_DTYPE_BF16;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -879,6 +882,33 @@ extern "C" int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
                         activation, reduce, slope, coef_keep, feat_keep, seed, out, agg, pos, lse, q, ws, n_slots, stream);
 }
 
+// Step words of gatmi_dropout_step_source, one per device.  The counter lets the launch path skip the
+// device query while no word is registered anywhere (the usual case).
+namespace {
+std::atomic<const uint64_t *> step_word_of_device[kMaxDevices] = {};
+std::atomic<int> step_words_registered{0};
+}  // namespace
+
+const uint64_t *gatmi::dropout_step_source() {
+    if (step_words_registered.load(std::memory_order_acquire) == 0) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    return step_word_of_device[dev].load(std::memory_order_acquire);
+}
+
+extern "C" int gatmi_dropout_step_source(const uint64_t *device_word) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(GATMI_EHIP, "dropout_step_source: hipGetDevice: %s", hipGetErrorString(e));
+    GATMI_REQUIRE(dev >= 0 && dev < kMaxDevices, GATMI_EUNSUPPORTED, "dropout_step_source: device ordinal %d (at most %d devices)", dev, kMaxDevices);
+    GATMI_REQUIRE((reinterpret_cast<uintptr_t>(device_word) & 7u) == 0, GATMI_EALIGN, "dropout_step_source: the word is not 8-byte aligned");
+    const uint64_t *old = step_word_of_device[dev].exchange(device_word, std::memory_order_acq_rel);
+    step_words_registered.fetch_add((device_word ? 1 : 0) - (old ? 1 : 0), std::memory_order_acq_rel);
+    return GATMI_OK;
+}
+
+extern "C" uint64_t gatmi_dropout_step_multiplier(void) { return kSeedStepMul; }
+
 extern "C" size_t gatmi_gat_bwd_node_ws_floats(int32_t H, int32_t dp) { return (size_t)kNodeBlocks * (size_t)H * dp; }
 
 extern "C" int gatmi_gat_bwd_node(int64_t n_dst, int32_t H, int32_t dp,
@@ -948,7 +978,7 @@ extern "C" int gatmi_gat_bwd_csc(int64_t n_src, int32_t H, int32_t dp,
                   "gat_bwd_csc: row strides ldg=%lld (>= hd, multiple of 4) lds=%lld (>= 3H)", (long long)ldg, (long long)lds);
     a.g = g; a.ldg = ldg; a.stats = stats; a.lds = lds; a.feat = feat; a.f2 = f2; a.la2 = logit_a2; a.lb2 = logit_b2; a.df1 = df1; a.a1 = a1; a.a2 = a2;
     a.dfeat = dfeat; a.df2 = df2; a.ws = ws;
-    a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
+    a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.seed_step = (coef_keep < 1.f || feat_keep < 1.f) ? dropout_step_source() : nullptr;
     const bool drop = coef_keep < 1.f || feat_keep < 1.f;
     GATMI_REQUIRE(g_dtype == GATMI_DTYPE_F32 || g_dtype == GATMI_DTYPE_BF16, GATMI_EUNSUPPORTED, "gat_bwd_csc: g_dtype %d", g_dtype);
     const bool bf16 = g_dtype == GATMI_DTYPE_BF16;

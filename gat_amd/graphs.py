@@ -5,10 +5,36 @@ read-back), so a step built from its operators captures as it is.  At Cora's siz
 forward + backward is about 25 launches of a few microseconds each; eager execution is bound by
 the host issuing them, the replay is not.
 """
+import contextlib
+
 import torch
 
+from . import _lib
 
-def capture(step, warmup=3):
+_MASK64 = (1 << 64) - 1
+
+
+def stepped_seed(seed, step):
+    """The seed a kernel uses when it reads `step` from a registered step word
+    (gatmi_dropout_step_source): seed + step * multiplier, mod 2^64."""
+    return (int(seed) + int(step) * int(_lib.lib.gatmi_dropout_step_multiplier())) & _MASK64
+
+
+@contextlib.contextmanager
+def dropout_step_word(word):
+    """While the block runs, every dropout launch issued on the current device carries the address of
+    `word` (a one-element int64 tensor on that device) and reads it when the kernel runs."""
+    if word.dtype != torch.int64 or word.numel() != 1 or not word.is_cuda:
+        raise ValueError("the step word is a one-element int64 tensor on the GPU")
+    with torch.cuda.device(word.device):
+        _lib.call("gatmi_dropout_step_source", word.data_ptr())
+        try:
+            yield word
+        finally:
+            _lib.call("gatmi_dropout_step_source", None)
+
+
+def capture(step, warmup=3, fresh_dropout=True):
     """Run `step()` `warmup` times on a side stream (allocator warm-up, lazy initialisations, the
     one-off mask statistics of the dense layer), capture one more call into a HIP graph and return
     (replay, result): `replay()` re-runs the captured kernels on the tensors the capture used — update
@@ -16,17 +42,36 @@ def capture(step, warmup=3):
     and `result` is whatever the captured call returned.
 
     Dropout: the kernels receive the dropout seed BY VALUE (drawn on the host when the step is
-    issued), so a captured step replays the SAME coefficient and projected-feature masks
-    (utils/layers.py:20,22) on every replay; only torch's own dropout of the layer input (:9)
-    advances its generator under replay.  Capture steps whose dropout rates are 0 (evaluation, the
-    benchmarks) or accept fixed masks; for fresh masks every step run eagerly."""
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(warmup):
-            step()
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        result = step()
-    return graph.replay, result
+    issued), and a graph freezes kernel arguments.  With `fresh_dropout` (default) the captured
+    launches therefore also carry the address of a step word on the device, the captured region starts
+    by adding one to it, and the kernels mix it into their seed when they run: every replay draws new
+    coefficient and projected-feature masks (utils/layers.py:20,22), the forward and backward launches
+    of one replay agree, and `replay.step_word` holds the count (gat_amd.graphs.stepped_seed gives the
+    seed a replay used).  torch's own dropout of the layer input (:9) advances its generator under
+    replay by itself.  `fresh_dropout=False` replays the masks of the captured call unchanged."""
+    device = torch.device("cuda", torch.cuda.current_device())
+    word = torch.zeros(1, dtype=torch.int64, device=device) if fresh_dropout else None
+    scope = dropout_step_word(word) if fresh_dropout else contextlib.nullcontext()
+
+    def one():
+        if word is not None:
+            word.add_(1)
+        return step()
+
+    with scope:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                one()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            result = one()
+
+    def replay():
+        graph.replay()
+
+    replay.graph = graph
+    replay.step_word = word          # kept alive with the graph: the captured kernels read it
+    return replay, result

@@ -28,8 +28,11 @@ class TFAdam(torch.optim.Optimizer):
     first step).  For gradients of the size an L2 penalty alone produces the two take visibly
     different steps, so the drop-in keeps TensorFlow's form."""
 
-    def __init__(self, params, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-8):
-        super().__init__(params, dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps))
+    def __init__(self, params, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-8, capturable=False):
+        """capturable: keep the step count on the device and form lr_t there, so that step() issues
+        the same launches with the same arguments every time and can be replayed from a HIP graph
+        (gat_amd.graphs.capture); the host-side count of the default mode would be frozen at capture."""
+        super().__init__(params, dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps, capturable=capturable))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -45,11 +48,18 @@ class TFAdam(torch.optim.Optimizer):
                 st = self.state[p]
                 if not st:
                     st["t"], st["m"], st["v"] = 0, torch.zeros_like(p), torch.zeros_like(p)
-            t = self.state[ps[0]]["t"] + 1
-            for p in ps:
-                self.state[p]["t"] = t
             b1, b2 = group["beta1"], group["beta2"]
-            lr_t = group["lr"] * (1.0 - b2 ** t) ** 0.5 / (1.0 - b1 ** t)
+            if group["capturable"]:
+                if "t_dev" not in group:
+                    group["t_dev"] = torch.zeros((), dtype=torch.float64, device=ps[0].device)
+                t = group["t_dev"]
+                t.add_(1.0)
+                lr_t = (group["lr"] * torch.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)).to(torch.float32)
+            else:
+                t = self.state[ps[0]]["t"] + 1
+                for p in ps:
+                    self.state[p]["t"] = t
+                lr_t = group["lr"] * (1.0 - b2 ** t) ** 0.5 / (1.0 - b1 ** t)
             gs = [p.grad for p in ps]
             ms = [self.state[p]["m"] for p in ps]
             vs = [self.state[p]["v"] for p in ps]
@@ -59,7 +69,12 @@ class TFAdam(torch.optim.Optimizer):
             torch._foreach_addcmul_(vs, gs, gs, value=1.0 - b2)
             den = torch._foreach_sqrt(vs)
             torch._foreach_add_(den, group["eps"])
-            torch._foreach_addcdiv_(ps, ms, den, value=-lr_t)
+            if group["capturable"]:
+                upd = torch._foreach_div(ms, den)
+                torch._foreach_mul_(upd, lr_t)               # lr_t is a tensor on the device here
+                torch._foreach_sub_(ps, upd)
+            else:
+                torch._foreach_addcdiv_(ps, ms, den, value=-lr_t)
         return loss
 
 
@@ -169,12 +184,12 @@ class BaseGAttN:
         return l2_coef * sum(0.5 * (p * p).sum() for p in parameters)
 
     @staticmethod
-    def training(parameters, lr, l2_coef):
+    def training(parameters, lr, l2_coef, capturable=False):
         """base_gattn.py:75-88 as (optimizer, penalty_fn).  Adam at a CONSTANT rate: the reference
         builds an exponential-decay schedule (:82) but never passes global_step to minimize (:86),
-        so the step counter stays 0 and the rate never decays."""
+        so the step counter stays 0 and the rate never decays.  capturable: see TFAdam."""
         parameters = list(parameters)
-        opt = TFAdam(parameters, lr=lr)
+        opt = TFAdam(parameters, lr=lr, capturable=capturable)
         return opt, (lambda: BaseGAttN.l2_penalty(parameters, l2_coef))
 
 

@@ -237,6 +237,21 @@ int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
                           float slope, float coef_keep, float feat_keep, uint64_t seed,
                           float *out, float *agg, float *pos, float *lse, float *q, void *stream);
 
+/* Dropout under HIP-graph replay.  NO counterpart in the reference (TensorFlow draws its masks inside
+ * the session, utils/layers.py:9,20,22).  Every entry point takes its dropout seed by value, and a HIP
+ * graph freezes kernel arguments at capture: a captured training step would replay one set of masks.
+ * After gatmi_dropout_step_source(word), every launch with dropout switched on (a keep probability
+ * below 1) that is issued on the CURRENT device, from any thread, also carries `word` — the address of
+ * a 64-bit integer in that device's memory, 8-byte aligned — and its kernels read it when they run:
+ * they use seed + *word * gatmi_dropout_step_multiplier() (mod 2^64) in place of seed.  Bump the word
+ * on the stream before each step (inside the captured region, so that every replay does) and each
+ * step draws fresh masks; forward and backward launches of one step must see the same value.
+ * word = NULL ends it for later launches; launches already captured keep reading the word they were
+ * captured with, which must stay allocated for as long as they can run.  With no word registered the
+ * masks are exactly those of the seed passed (bit-identical to a library without this call). */
+int gatmi_dropout_step_source(const uint64_t *device_word);
+uint64_t gatmi_dropout_step_multiplier(void);
+
 /* Backward, per-destination part (no gather).  From dOut and the saved forward tensors:
  *   g [n_dst, hd]    = dOut * activation'(out)              (dOut / H per head for mean), row stride ldg floats;
  *       g16: the same rows in bf16 (row stride ldg16 bf16 elements) for gatmi_gat_bwd_csc's gather; either of
