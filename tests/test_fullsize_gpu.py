@@ -8,6 +8,11 @@ entries that go through the split-and-merge path), where the oracle would take f
                                                                 df1 comes from the forward pass's
                                                                 positive-part sums, df2 from the CSC sweep)
   * the layer is deterministic: two runs agree bit for bit
+
+and, value for value against the oracle on sampled nodes: an output row depends only on the row's
+own neighbour list, and dX_j only on the rows that read j, so the oracle evaluated on the sub-graph
+induced by a sample of rows (with their complete neighbour lists) reproduces exactly those rows of
+the full-size result — hub rows and a column long enough to be split included.
 """
 import numpy as np
 import pytest
@@ -93,6 +98,156 @@ def test_gradient_checksums_and_determinism(big):
     l2, r2 = df2.double().sum(0), df1.double().sum(0)
     s2 = df2.double().abs().sum(0) + df1.double().abs().sum(0)
     assert ((l2 - r2).abs() <= 1e-6 * s2).all(), ((l2 - r2).abs() / s2).max().item()
+
+
+def _induced(g, rows):
+    """Sub-graph that keeps the complete neighbour lists of `rows` and nothing else: (nodes, rowptr,
+    col) with `nodes` the sorted global ids of the rows and of every source they read, ids relabelled
+    to positions in `nodes`, rows outside `rows` empty."""
+    rows = np.unique(np.asarray(rows, dtype=np.int64))
+    lo, hi = g.rowptr_host[rows], g.rowptr_host[rows + 1]
+    lens = hi - lo
+    pos = np.repeat(lo - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens) + np.arange(int(lens.sum()))
+    cols = g.col[torch.as_tensor(pos, device=g.col.device)].cpu().numpy().astype(np.int64)
+    nodes = np.unique(np.concatenate([rows, cols]))
+    sub_len = np.zeros(len(nodes), dtype=np.int64)
+    sub_len[np.searchsorted(nodes, rows)] = lens
+    rowptr = np.concatenate([[0], np.cumsum(sub_len)])
+    return nodes, rowptr, np.searchsorted(nodes, cols).astype(np.int32)     # rows ascending: entries already in row order
+
+
+def _layer_and_input(dev, n):
+    from gat_amd import synth
+    return synth.glorot_layer(F, H, D, 7, dev, zero_bias=False), synth.normal((n, F), 5, dev)
+
+
+def test_sampled_rows_match_the_oracle_at_full_size(big):
+    """Forward values of 300 random rows and the three longest rows (tens of thousands of entries: the
+    split-and-merge path) against oracle.ref_numpy.gat_layer_csr on their induced sub-graph."""
+    from gat_amd import ops
+    from oracle import ref_numpy
+    from tests.util import assert_close
+    g, dev = big
+    n = g.n_dst
+    p, x = _layer_and_input(dev, n)
+    out = ops.sparse_gat_layer(x, p["W"], p["a1"], p["a2"], p["b1"], p["b2"], p["bias"], g, ops.make_cfg(H, D, "elu"))
+    deg = np.diff(g.rowptr_host)
+    hubs = np.argsort(deg)[-3:]
+    assert deg[hubs].min() > g.chunk, "the longest rows are expected to be split rows"
+    rows = np.unique(np.concatenate([hubs, np.random.default_rng(0).choice(n, 300, replace=False)]))
+    nodes, rowptr, col = _induced(g, rows)
+    layer = {k: v.detach().cpu().double().numpy() for k, v in p.items()}
+    ref = ref_numpy.gat_layer_csr(x[torch.as_tensor(nodes, device=dev)].cpu().double().numpy(), layer, rowptr, col)
+    got = out[torch.as_tensor(rows, device=dev)].cpu().numpy()
+    assert_close(got, ref[np.searchsorted(nodes, rows)], what="sampled rows of the full-size forward pass")
+
+
+def _readers(g, js):
+    """Every row that reads one of the sources js (their CSC columns), and js themselves."""
+    js = np.asarray(js, dtype=np.int64)
+    lo, lens = g.colptr_host[js], np.diff(g.colptr_host)[js]
+    pos = np.repeat(lo - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens) + np.arange(int(lens.sum()))
+    return np.unique(np.concatenate([js, g.rowidx[torch.as_tensor(pos, device=g.rowidx.device)].cpu().numpy().astype(np.int64)]))
+
+
+def _within_budget(g, candidates, budget, at_least):
+    """The longest prefix of `candidates` whose readers hold at most `budget` entries between them."""
+    rdeg = np.diff(g.rowptr_host)
+    kept, total = [], 0
+    for j in candidates:
+        cost = int(rdeg[_readers(g, [j])].sum())
+        if kept and total + cost > budget:
+            break
+        kept.append(int(j))
+        total += cost
+    assert len(kept) >= at_least, "only %d of the sampled nodes fit the oracle's budget of %d entries" % (len(kept), budget)
+    return kept
+
+
+def _check_sampled_dx(g, dev, targets, what):
+    from gat_amd import ops, synth
+    from oracle import ref_torch
+    from tests.util import assert_close
+    n = g.n_dst
+    p, x = _layer_and_input(dev, n)
+    x.requires_grad_(True)
+    dout = synth.normal((n, H * D), 8, dev)
+    out = ops.sparse_gat_layer(x, p["W"], p["a1"], p["a2"], p["b1"], p["b2"], p["bias"], g, ops.make_cfg(H, D, "elu"))
+    out.backward(dout)
+    targets = np.unique(np.asarray(targets, dtype=np.int64))
+    rows = _readers(g, targets)
+    nodes, rowptr, col = _induced(g, rows)
+    assert len(col) < 3_000_000, "sub-graph of %d entries is too large for the float64 oracle" % len(col)
+    pos_rows, pos_t = np.searchsorted(nodes, rows), np.searchsorted(nodes, targets)
+    xs = x.detach()[torch.as_tensor(nodes, device=dev)].cpu().double().requires_grad_(True)
+    ds = torch.zeros(len(nodes), H * D, dtype=torch.float64)
+    ds[pos_rows] = dout[torch.as_tensor(rows, device=dev)].cpu().double()
+    pp = {k: v.detach().cpu().double() for k, v in p.items()}
+    ref_torch.layer_csr(xs, pp, torch.as_tensor(rowptr), torch.as_tensor(col), "elu", "concat").backward(ds)
+    got = x.grad[torch.as_tensor(targets, device=dev)].cpu().numpy()
+    assert_close(got, xs.grad[pos_t].numpy(), atol_scale=5e-6, what=what)
+
+
+def test_sampled_input_gradients_match_the_oracle_at_full_size(big):
+    """dX of random nodes (as many as keep the sub-graph under 2 M entries) against the float64 autograd
+    oracle on the sub-graph induced by every row that reads them (each with its complete neighbour list)."""
+    g, dev = big
+    cdeg = np.diff(g.colptr_host)
+    targets = np.random.default_rng(1).choice(np.nonzero(cdeg <= 400)[0], 150, replace=False)
+    _check_sampled_dx(g, dev, _within_budget(g, targets, 2_000_000, 20), "sampled rows of the full-size input gradient")
+
+
+def test_sampled_input_gradient_of_a_split_column_at_full_size():
+    """The same for a node whose column is cut into pieces and merged.  With the benchmark's work-item
+    size the shortest split column has 4 700 readers holding 7.7 M entries between them, too many for
+    the float64 oracle; the same graph cut into work items of 128 entries splits columns of a few
+    hundred entries, whose readers the oracle handles."""
+    from gat_amd import CSRGraph, synth
+    dev = torch.device("cuda:0")
+    n, e = synth.PRODUCTS_NODES, synth.PRODUCTS_EDGES
+    dst, src = synth.rmat_graph(n, e, 4, dev)
+    g = CSRGraph.from_device_coo(dst, src, n, n, chunk=128)
+    del dst, src
+    split = g.split_csc.cpu().numpy()
+    assert len(split) > 0
+    cdeg = np.diff(g.colptr_host)
+    cols = np.unique(split[:, 0])                       # first field of a split record: the column it belongs to
+    cols = _within_budget(g, cols[np.argsort(cdeg[cols])][:8], 2_000_000, 1)
+    assert cdeg[cols].min() > g.chunk
+    _check_sampled_dx(g, dev, cols, "input gradient of split columns at full size")
+
+
+def test_sampled_rows_and_gradients_at_one_gpus_share_of_the_two_billion_edge_graph():
+    """BASELINE.json configs[4] gives each of 8 GPUs 12.5 M rows / 262.5 M entries (feature-table offsets
+    pass 2^31 elements, gathered tables are 3 to 5 GB): the same sampled comparisons with the oracle on that graph, built and run on
+    one GPU."""
+    from gat_amd import CSRGraph, ops, synth
+    from oracle import ref_numpy
+    from tests.util import assert_close
+    dev = torch.device("cuda:0")
+    n, e = 12_500_000, 250_000_000
+    if torch.cuda.mem_get_info()[0] < 120 * 2 ** 30:
+        pytest.skip("needs about 100 GiB of free device memory")
+    dst, src = synth.rmat_graph(n, e, 4, dev)
+    g = CSRGraph.from_device_coo(dst, src, n, n)
+    del dst, src
+    assert g.n_dst * H * D * 3 >= 2 ** 31
+    p, x = _layer_and_input(dev, n)
+    with torch.no_grad():
+        out = ops.sparse_gat_layer(x, p["W"], p["a1"], p["a2"], p["b1"], p["b2"], p["bias"], g, ops.make_cfg(H, D, "elu"))
+    deg = np.diff(g.rowptr_host)
+    last = np.nonzero(deg > 1)[0][-50:]                    # rows at the far end of the entry array
+    rows = np.unique(np.concatenate([np.argsort(deg)[-2:], last, np.random.default_rng(2).choice(n, 200, replace=False)]))
+    nodes, rowptr, col = _induced(g, rows)
+    layer = {k: v.detach().cpu().double().numpy() for k, v in p.items()}
+    ref = ref_numpy.gat_layer_csr(x[torch.as_tensor(nodes, device=dev)].cpu().double().numpy(), layer, rowptr, col)
+    assert_close(out[torch.as_tensor(rows, device=dev)].cpu().numpy(), ref[np.searchsorted(nodes, rows)],
+                 what="sampled rows of the forward pass, 262.5 M entries")
+    del out
+    cdeg = np.diff(g.colptr_host)
+    cand = np.random.default_rng(3).choice(np.nonzero(cdeg <= 400)[0], 100, replace=False)
+    cand = np.concatenate([np.nonzero((cdeg > 0) & (cdeg <= 50))[0][-5:], cand])        # columns at the far end too
+    _check_sampled_dx(g, dev, _within_budget(g, cand, 2_000_000, 10), "sampled rows of the input gradient, 262.5 M entries")
 
 
 def test_dense_batch_routes_agree_at_full_size():
