@@ -1,4 +1,4 @@
-"""One products-sized shard of a world-times larger R-MAT graph, seen from rank 0 and run alone:
+"""One products-sized shard (or, with a leading `rmat2b` argument, one 12.5 M-row / 262.5 M-entry shard) of a world-times larger R-MAT graph, seen from rank 0 and run alone:
   * unique remote source rows (halo): what each rank receives per forward exchange and returns per
     backward exchange in halo="exchange" mode, and what it stores once in halo="replicate" mode;
   * the compute time of the step in replicate mode (owned + halo rows projected locally), measured
@@ -78,8 +78,11 @@ def _kernel_breakdown(step, iters=5):
 def main():
     dev = torch.device("cuda:0")
     n_own, e_own = synth.PRODUCTS_NODES, synth.PRODUCTS_EDGES
+    argv = sys.argv[1:]
+    if argv and argv[0] == "rmat2b":                     # one GPU's share of BASELINE.json configs[4] instead of the products shape
+        n_own, e_own, argv = 12_500_000, 250_000_000, argv[1:]
     F, H, D = 100, 8, 8
-    for world in ([int(a) for a in sys.argv[1:]] or (1, 2, 4, 8)):
+    for world in ([int(a) for a in argv] or (1, 2, 4, 8)):
         n = n_own * world
         part = np.arange(world + 1, dtype=np.int64) * n_own
         dst, src = synth.rmat_graph(n, e_own, 4, dev, row_range=(0, n_own))
