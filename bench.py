@@ -49,12 +49,12 @@ def parse():
                     help="products: the headline (default), per GPU the ogbn-products shape; rmat2b: per GPU one eighth of "
                          "configs[4] (12.5 M rows, 250 M edges + self-loops: at --gpus 8 the 100 M-node / 2 B-edge graph); "
                          "cora: the two-layer Cora network, GPU vs the CPU restatement")
-    ap.add_argument("--halo", choices=["exchange", "replicate", "both"], default="exchange",
-                    help="N > 1 only.  exchange (default, the measured configuration): Wh / f2 rows of the halo sources and "
+    ap.add_argument("--halo", choices=["exchange", "replicate", "both"], default="both",
+                    help="N > 1 only.  exchange (the measured configuration, the line's value): Wh / f2 rows of the halo sources and "
                          "their gradients travel every step (RCCL all-to-all); replicate: a first layer's constant input rows "
                          "of the halo sources are fetched once at set-up and projected locally, a step communicates only the "
-                         "all-reduce of the parameter gradients; both: exchange is the line's value, the replicate-mode step "
-                         "is reported beside it under 'replicate_mode'")
+                         "all-reduce of the parameter gradients; both (default): exchange is the line's value, the replicate-mode step "
+                         "is timed afterwards and reported beside it under 'replicate_mode'")
     ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
                     help="N > 1, exchange: run the all-to-alls on a communication stream beside the sweeps that do not need "
                          "them (on), or exchanges and kernels in turn (off).  The overlap costs some kernel time (every row's "
