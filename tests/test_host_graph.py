@@ -229,3 +229,15 @@ def test_phased_work_items_cover_each_part_once_and_pair_their_slots(seed, chunk
     bad[7] = rowptr[8] + 1
     rc = _lib.lib.gatmi_work_items_phased_count(n, ptr(rowptr), ptr(bad), chunk, ctypes.byref(na), ctypes.byref(nb), ctypes.byref(ns), ctypes.byref(nl))
     assert rc == -1 and "cut" in _lib.last_error()
+
+
+def test_stepped_seed_is_the_kernels_seed_arithmetic():
+    """gat_amd.graphs.stepped_seed restates on the host what a kernel does with a registered step word:
+    seed + step * multiplier modulo 2^64, with an odd multiplier (so that steps never repeat a seed)."""
+    from gat_amd import _lib, graphs
+    mul = int(_lib.lib.gatmi_dropout_step_multiplier())
+    assert mul % 2 == 1 and mul > 2 ** 63
+    assert graphs.stepped_seed(123, 0) == 123
+    assert graphs.stepped_seed(123, 1) == (123 + mul) % 2 ** 64
+    assert graphs.stepped_seed(2 ** 64 - 1, 2 ** 64 - 1) == (2 ** 64 - 1 + (2 ** 64 - 1) * mul) % 2 ** 64
+    assert len({graphs.stepped_seed(7 + h, s) for h in range(4) for s in range(1000)}) == 4000
