@@ -78,6 +78,26 @@ class TFAdam(torch.optim.Optimizer):
         return loss
 
 
+class _L2Penalty(torch.autograd.Function):
+    """coef * sum_v 0.5 ||v||^2 over a list of tensors with a handful of launches in each direction
+    (horizontally fused norms forward, one fused scaling backward: d/dv = coef * v).  Written per
+    tensor, the penalty of a 13-variable network is about a hundred launches of a few microseconds,
+    a visible share of a Cora-sized training step even when the step is replayed from a HIP graph."""
+
+    @staticmethod
+    def forward(ctx, coef, *params):
+        ctx.coef = coef
+        ctx.save_for_backward(*params)
+        sq = torch.stack(torch._foreach_norm([p.detach() for p in params])).double().square().sum()
+        return (sq * (0.5 * coef)).to(params[0].dtype)
+
+    @staticmethod
+    def backward(ctx, grad):
+        params = ctx.saved_tensors
+        scale = grad * ctx.coef
+        return (None, *torch._foreach_mul(list(params), scale))
+
+
 class BaseGAttN:
     """Loss / metric / optimiser helpers of models/base_gattn.py."""
 
@@ -181,7 +201,7 @@ class BaseGAttN:
         """base_gattn.py:77-79: l2_coef * sum of tf.nn.l2_loss(v) = 0.5 * ||v||^2 over every
         trainable variable (the name filter there compares against names no TF variable has, so
         biases are included too)."""
-        return l2_coef * sum(0.5 * (p * p).sum() for p in parameters)
+        return _L2Penalty.apply(float(l2_coef), *parameters)
 
     @staticmethod
     def training(parameters, lr, l2_coef, capturable=False):
