@@ -250,13 +250,15 @@ def timed_steps(step, args, world, dev, lib):
     prof = EventProfiler()
     raw_call = lib.call
     lib.call = prof.wrap(raw_call)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    lib.call = raw_call
+    try:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        lib.call = raw_call
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -319,23 +321,29 @@ def main():
                 t_ov, _ = timed_steps(bench.step_fn("exchange", overlap=ov), trial, world, dev, _lib)     # max over ranks: same choice everywhere
                 overlap_trial["on" if ov else "off"] = round(t_ov / trial.steps * 1e3, 4)
             overlap = overlap_trial["on"] <= overlap_trial["off"]
+        replicate_error = None
         for mode in modes:
-            step = bench.step_fn(mode, overlap=overlap)
-            bench.pg.exchange.enable_timing()
-            elapsed, ksum = timed_steps(step, args, world, dev, _lib)
-            torch.cuda.synchronize()
-            a2a_total_ms, sent, received, n_a2a = bench.pg.exchange.a2a_summary()
-            per_step = args.steps + args.warmup          # the exchange's events cover the warm-up steps too
-            results[mode] = (elapsed, ksum, {
-                "a2a_ms": round(a2a_total_ms / per_step, 4), "a2a_per_step": n_a2a // per_step,
-                "bytes_sent_per_step": sent // per_step, "bytes_received_per_step": received // per_step})
-            bench.release(mode)
+            try:
+                step = bench.step_fn(mode, overlap=overlap)
+                bench.pg.exchange.enable_timing()
+                elapsed, ksum = timed_steps(step, args, world, dev, _lib)
+                torch.cuda.synchronize()
+                a2a_total_ms, sent, received, n_a2a = bench.pg.exchange.a2a_summary()
+                per_step = args.steps + args.warmup          # the exchange's events cover the warm-up steps too
+                results[mode] = (elapsed, ksum, {
+                    "a2a_ms": round(a2a_total_ms / per_step, 4), "a2a_per_step": n_a2a // per_step,
+                    "bytes_sent_per_step": sent // per_step, "bytes_received_per_step": received // per_step})
+                bench.release(mode)
+            except Exception as exc:          # the second leg of --halo both must not cost the line its measured value
+                if mode == modes[0]:
+                    raise
+                replicate_error = "%s: %s" % (type(exc).__name__, exc)
         elapsed, ksum, comm = results[modes[0]]
         dist_info = dict(comm, backend=("rccl" if backend == "nccl" else backend), world_size=dist.get_world_size(),
                          halo=modes[0], overlap=(modes[0] == "exchange" and overlap), overlap_trial_ms=overlap_trial,
                          n_halo=bench.pg.n_halo, n_send=bench.pg.exchange.n_send,
                          local_entry_fraction=round(bench.pg.local_entries / max(1, E_rank), 4))
-        if len(modes) == 2:
+        if len(modes) == 2 and "replicate" in results:
             e2, k2, c2 = results["replicate"]
             replicate_line = (e2, k2, c2)
     else:
@@ -426,6 +434,8 @@ def main():
             ms2 = e2 / args.steps * 1e3
             line["replicate_mode"] = dict(c2, ms_per_step=round(ms2, 4), value=E_total / (ms2 * 1e-3),
                                           kernels_ms={k: round(v[0] * v[1] / args.steps, 4) for k, v in sorted(k2.items())})
+        elif world > 1 and replicate_error:
+            line["replicate_mode"] = {"error": replicate_error}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

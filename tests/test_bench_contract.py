@@ -1,0 +1,44 @@
+"""The bench line's contract, checked on the lines kept under profiles/ (written by bench.py on the
+GPU box): every key the driver and the reviewers read is there, with the right type, and the derived
+figures are consistent with each other."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(name):
+    with open(os.path.join(ROOT, "profiles", name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+def test_single_gpu_line_carries_the_contract():
+    d = _line("r02_bench_n1.json")
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), key
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["unit"] == "edges/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # achieved = algorithmic bytes of one launch / its average duration, traffic = counter bytes of one launch
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_ms"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
+    assert r["traffic"] is None or (isinstance(r["traffic"], int) and 0.3 * r["alg_bytes_per_launch"] < r["traffic"] < 1.5 * r["alg_bytes_per_launch"])
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "edges/s" and c["sample"]
+    # value = entries / step time; the entry points' HIP-event times fit inside the step
+    entries = int(d["config"]["workload"].split(" nodes, ")[1].split(" edge entries")[0])
+    assert abs(d["value"] - entries / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert sum(d["kernels_ms"].values()) <= d["ms_per_step"] * 1.001
+
+
+def test_multi_gpu_rehearsal_line_names_what_travelled():
+    d = _line("r02_rehearsal_gloo_2ranks_one_gpu.json")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["backend"] == "gloo"
+    x = d["dist"]
+    assert x["halo"] == "exchange" and x["world_size"] == 2 and x["n_halo"] > 0
+    assert x["bytes_sent_per_step"] > 0 and x["a2a_ms"] > 0 and x["a2a_per_step"] >= 2
+    assert set(x["overlap_trial_ms"]) == {"on", "off"}
+    assert d["replicate_mode"]["bytes_sent_per_step"] == 0 and d["replicate_mode"]["value"] > 0
