@@ -1322,11 +1322,18 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
             __syncthreads();                              // the list area is free again
         }
     }
+    // `graph_soft`: some row of this graph carries biases that must be added to its logits (its flag word is
+    // set).  Hard masks, the usual case, have none: the list building below then skips the flag words altogether.
+    int soft_seen = 0;
     {
         const uint32_t *src3 = a.present + b * N * (int64_t)W;
-        for (int e = threadIdx.x; e < N * W; e += blockDim.x) ps[e] = src3[e];
+        for (int e = threadIdx.x; e < N * W; e += blockDim.x) {
+            const uint32_t w = src3[e];
+            ps[e] = w;
+            soft_seen |= (e % W == W - 1) ? (int)w : 0;
+        }
     }
-    __syncthreads();
+    const bool graph_soft = __syncthreads_or(soft_seen) != 0;
     const int c8 = lane >> 3, s8 = lane & 7;
     const int head8 = s8 / LPH8;
     const float *gl = gs + s8 * 8;
@@ -1346,15 +1353,26 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
             // bit r of `bits`: destination row 16 r + sub visited column jcol; `softs`: and needs its bias value
             uint32_t bits = 0, softs = 0;
             const int wj = jcol >> 5, bj = jcol & 31;
+            if (graph_soft) {
 #pragma unroll
-            for (int r = 0; r < kGraphBwdRows; ++r) {
-                const int i = 16 * r + sub;
-                if (16 * r < N) {                         // uniform
-                    const int ic = min(i, N - 1);
-                    const uint32_t word = ps[ic * W + wj], flag = ps[ic * W + W - 1];
-                    const uint32_t bit = i < N ? (word >> bj) & 1u : 0u;
-                    bits |= bit << r;
-                    softs |= (bit & flag) << r;
+                for (int r = 0; r < kGraphBwdRows; ++r) {
+                    const int i = 16 * r + sub;
+                    if (16 * r < N) {                         // uniform
+                        const int ic = min(i, N - 1);
+                        const uint32_t word = ps[ic * W + wj], flag = ps[ic * W + W - 1];
+                        const uint32_t bit = i < N ? (word >> bj) & 1u : 0u;
+                        bits |= bit << r;
+                        softs |= (bit & flag) << r;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < kGraphBwdRows; ++r) {
+                    const int i = 16 * r + sub;
+                    if (16 * r < N) {                         // uniform
+                        const uint32_t word = ps[min(i, N - 1) * W + wj];
+                        bits |= (i < N ? (word >> bj) & 1u : 0u) << r;
+                    }
                 }
             }
             const int cntl = __popc(bits);
