@@ -30,7 +30,7 @@ def test_single_gpu_line_carries_the_contract():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "edges/s" and c["sample"]
     # value = entries / step time; the entry points' HIP-event times fit inside the step
     entries = int(d["config"]["workload"].split(" nodes, ")[1].split(" edge entries")[0])
-    assert abs(d["value"] - entries / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - entries / (d["ms_per_step"] * 1e-3)) < 1e-5 * d["value"]
     assert sum(d["kernels_ms"].values()) <= d["ms_per_step"] * 1.001
 
 
