@@ -111,20 +111,35 @@ __device__ __forceinline__ uint64_t seed_now(const Args &a) {
     return a.seed_step ? a.seed + *a.seed_step * kSeedStepMul : a.seed;
 }
 
-// feature-dropout of one float4 of row j (columns c0..c0+3): utils/layers.py:22
+// Feature dropout (utils/layers.py:22): ONE hash serves four consecutive elements of the [rows, hd] table,
+// 16 bits each — the keep probability is resolved to 2^-16 — because the row kernels apply it to every row they
+// gather: hashed element by element it doubled the forward kernel's time at the reference's rate of 0.6.
+// Element e = row * hd + column belongs to group e >> 2 and takes bits 16 (e & 3) .. 16 (e & 3) + 15.
+__device__ __forceinline__ uint64_t feat_group_bits(uint64_t seed, uint64_t group) {
+    uint64_t z = group + (seed ^ kFeatSeedSalt) * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t feat_keep_threshold(float keep) { return (uint32_t)(keep * 65536.0f); }
+
+// feature-dropout of one float4 of row j (columns c0..c0+3, c0 and hd multiples of 4: one group)
 __device__ __forceinline__ float4 drop_feat(float4 v, uint64_t seed, int64_t j, int hd, int c0, float keep) {
-    const uint64_t base = (uint64_t)j * (uint64_t)hd + (uint64_t)c0;
+    const uint64_t z = feat_group_bits(seed, ((uint64_t)j * (uint64_t)hd + (uint64_t)c0) >> 2);
+    const uint32_t lo = (uint32_t)z, hi = (uint32_t)(z >> 32), thr = feat_keep_threshold(keep);
     const float inv = 1.0f / keep;
-    v.x = keep_mask(seed ^ kFeatSeedSalt, base + 0, keep) ? v.x * inv : 0.f;
-    v.y = keep_mask(seed ^ kFeatSeedSalt, base + 1, keep) ? v.y * inv : 0.f;
-    v.z = keep_mask(seed ^ kFeatSeedSalt, base + 2, keep) ? v.z * inv : 0.f;
-    v.w = keep_mask(seed ^ kFeatSeedSalt, base + 3, keep) ? v.w * inv : 0.f;
+    v.x = (lo & 0xffffu) < thr ? v.x * inv : 0.f;
+    v.y = (lo >> 16) < thr ? v.y * inv : 0.f;
+    v.z = (hi & 0xffffu) < thr ? v.z * inv : 0.f;
+    v.w = (hi >> 16) < thr ? v.w * inv : 0.f;
     return v;
 }
 
 // one element of the same mask (row j, column c)
 __device__ __forceinline__ float drop_feat1(float v, uint64_t seed, int64_t j, int hd, int c, float keep) {
-    return keep_mask(seed ^ kFeatSeedSalt, (uint64_t)j * (uint64_t)hd + (uint64_t)c, keep) ? v / keep : 0.f;
+    const uint64_t e = (uint64_t)j * (uint64_t)hd + (uint64_t)c;
+    const uint32_t field = (uint32_t)(feat_group_bits(seed, e >> 2) >> (16 * (e & 3))) & 0xffffu;
+    return field < feat_keep_threshold(keep) ? v / keep : 0.f;
 }
 
 // coefficient-dropout factor of entry (i, j) of graph b, head hg of a dense [B, N, N] batch:

@@ -204,7 +204,8 @@ int gatmi_proj_bwd_params_csr(const int64_t *xt_rowptr, const int32_t *xt_row, c
  *       pre-LeakyReLU logit, q = sum of alpha over those entries, lse = log sum exp of the row
  *   ws: gatmi_gat_fwd_ws_floats(n_slots, H, dp) floats when n_split > 0
  *   coef_keep / feat_keep in (0,1]: keep probabilities of layers.py:20 / :22 (1 = no dropout);
- *   masks are a counter-based hash of (seed, CSR entry position, head) / (seed, src, column). */
+ *   masks are a counter-based hash of (seed, CSR entry position, head) / (seed, src, column); the feature
+ *   mask draws one hash per four consecutive columns (16 bits each: keep probabilities resolve to 2^-16). */
 size_t gatmi_gat_fwd_ws_floats(int64_t n_slots, int32_t H, int32_t dp);
 int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
                   const int32_t *items, int64_t n_items, const int32_t *split, int64_t n_split,

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import ref_torch
-from tests.util import FEAT_SALT, assert_close, keep_mask_host
+from tests.util import assert_close, feat_keep_host
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +24,7 @@ def test_decoder_forward_and_gradient(B, N, F, activation, dropout):
     seed = 1234
     if dropout:
         out = ops.inner_product_decoder(zt, activation, dropout, seed=seed).reshape(-1)
-        mask = keep_mask_host(seed ^ FEAT_SALT, np.arange(B * N * F, dtype=np.uint64), 1.0 - dropout).reshape(B, N, F)
+        mask = feat_keep_host(seed, np.arange(B * N * F, dtype=np.uint64), 1.0 - dropout).reshape(B, N, F)
         assert abs((1.0 - mask.mean()) - dropout) < 0.05
         mask = torch.tensor(mask.astype(np.float64))
     else:

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import ref_numpy, ref_torch
-from tests.util import FEAT_SALT, assert_close, keep_mask_host, layer_params, random_graph
+from tests.util import assert_close, feat_keep_host, keep_mask_host, layer_params, random_graph
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,7 @@ def test_masks_replay_in_forward_and_backward(H, D, coef_drop, in_drop, storage)
     if in_drop > 0:
         cols = (np.arange(H)[:, None] * dp + np.arange(D)[None, :]).astype(np.uint64)          # padded column ids
         idx = np.arange(n, dtype=np.uint64)[:, None, None] * np.uint64(H * dp) + cols[None]
-        ft_mask = keep_mask_host(seed ^ FEAT_SALT, idx, 1.0 - in_drop).astype(np.float64)
+        ft_mask = feat_keep_host(seed, idx, 1.0 - in_drop).astype(np.float64)
         assert abs(ft_mask.mean() - (1.0 - in_drop)) < 0.03
     rp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
     rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
@@ -112,7 +112,7 @@ def test_dense_layer_masks_replay(B, N, H, D, coef_drop, in_drop, path):
     if in_drop > 0:
         cols = (np.arange(H)[:, None] * dp + np.arange(D)[None, :]).astype(np.uint64)
         idx = np.arange(B * N, dtype=np.uint64)[:, None, None] * np.uint64(H * dp) + cols[None]
-        ft_mask = keep_mask_host(seed ^ FEAT_SALT, idx, 1.0 - in_drop).astype(np.float64).reshape(B, N, H, D)
+        ft_mask = feat_keep_host(seed, idx, 1.0 - in_drop).astype(np.float64).reshape(B, N, H, D)
     rp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
     rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     ref = ref_torch.layer_dense(rx, rp, torch.tensor(bm), "elu", "concat",

@@ -76,6 +76,19 @@ def keep_mask_host(seed, idx, keep):
     return (r * np.float32(1.0 / 16777216.0)) < np.float32(keep)
 
 
+def feat_keep_host(seed, elem, keep):
+    """Host twin of drop_feat / drop_feat1 in gat_amd/csrc/device_common.h: element index e of the [rows, hd]
+    table belongs to group e >> 2, one splitmix64 per group, 16 bits per element against keep * 65536."""
+    elem = np.asarray(elem).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z = (elem >> np.uint64(2)) + (np.uint64(seed) ^ np.uint64(FEAT_SALT)) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    field = (z >> (np.uint64(16) * (elem & np.uint64(3)))) & np.uint64(0xffff)
+    return field < np.uint64(int(np.float32(keep) * np.float32(65536.0)))
+
+
 def sparse_dropout_masks(seed, n_entries, n, H, D, dp, coef_drop, in_drop):
     """Masks the CSR kernels draw: coefficients keyed on (CSR position, head) -> [E,H]; projected
     features keyed on (source, padded column) -> [n,H,D].  None where the rate is 0."""
@@ -86,7 +99,7 @@ def sparse_dropout_masks(seed, n_entries, n, H, D, dp, coef_drop, in_drop):
     if in_drop > 0:
         cols = (np.arange(H)[:, None] * dp + np.arange(D)[None, :]).astype(np.uint64)
         idx = np.arange(n, dtype=np.uint64)[:, None, None] * np.uint64(H * dp) + cols[None]
-        ft = keep_mask_host(seed ^ FEAT_SALT, idx, 1.0 - in_drop).astype(np.float64)
+        ft = feat_keep_host(seed, idx, 1.0 - in_drop).astype(np.float64)
     return coef, ft
 
 
@@ -101,7 +114,7 @@ def dense_dropout_masks(seed, B, N, H, D, dp, coef_drop, in_drop):
     if in_drop > 0:
         cols = (np.arange(H)[:, None] * dp + np.arange(D)[None, :]).astype(np.uint64)
         idx = np.arange(B * N, dtype=np.uint64)[:, None, None] * np.uint64(H * dp) + cols[None]
-        ft = keep_mask_host(seed ^ FEAT_SALT, idx, 1.0 - in_drop).astype(np.float64).reshape(B, N, H, D)
+        ft = feat_keep_host(seed, idx, 1.0 - in_drop).astype(np.float64).reshape(B, N, H, D)
     return coef, ft
 
 
