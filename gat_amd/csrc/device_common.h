@@ -85,16 +85,19 @@ __device__ __forceinline__ uint32_t or8_to_first(uint32_t w) {
     return w;
 }
 
-// Counter-based dropout mask: splitmix64 finaliser of (seed, index); keep when the top 24 bits,
-// read as a fraction in [0,1), fall below keep_prob.  The same function is restated on the host
-// by the tests to replay masks.
+// Counter-based dropout mask: a 32-bit integer mixer (two multiply / xor-shift rounds) of the 64-bit
+// (seed, index) pair folded to one word; keep when the top 24 bits, read as a fraction in [0,1), fall
+// below keep_prob.  About a dozen 32-bit operations: the mask is evaluated per entry and head inside the
+// gather kernels, where a 64-bit mixer (two 64-bit multiplies) was a visible share of the time at the
+// reference's dropout rates.  The same function is restated on the host by the tests to replay masks.
 __device__ __forceinline__ bool keep_mask(uint64_t seed, uint64_t idx, float keep_prob) {
-    uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    const uint32_t r = (uint32_t)(z >> 40);  // 24 bits
-    return (float)r * (1.0f / 16777216.0f) < keep_prob;
+    uint32_t x = ((uint32_t)idx ^ (uint32_t)seed) + ((uint32_t)(idx >> 32) ^ (uint32_t)(seed >> 32)) * 0x9E3779B9u;
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return (float)(x >> 8) * (1.0f / 16777216.0f) < keep_prob;
 }
 
 constexpr uint64_t kFeatSeedSalt = 0x5DEECE66Dull;
@@ -115,11 +118,19 @@ __device__ __forceinline__ uint64_t seed_now(const Args &a) {
 // 16 bits each — the keep probability is resolved to 2^-16 — because the row kernels apply it to every row they
 // gather: hashed element by element it doubled the forward kernel's time at the reference's rate of 0.6.
 // Element e = row * hd + column belongs to group e >> 2 and takes bits 16 (e & 3) .. 16 (e & 3) + 15.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    return x ^ (x >> 16);
+}
+// 64 bits for one group: the mixer of keep_mask on the folded (salted seed, group) pair, and once more on its result
 __device__ __forceinline__ uint64_t feat_group_bits(uint64_t seed, uint64_t group) {
-    uint64_t z = group + (seed ^ kFeatSeedSalt) * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+    const uint64_t s = seed ^ kFeatSeedSalt;
+    const uint32_t lo = mix32(((uint32_t)group ^ (uint32_t)s) + ((uint32_t)(group >> 32) ^ (uint32_t)(s >> 32)) * 0x9E3779B9u);
+    const uint32_t hi = mix32(lo + 0x9E3779B9u);
+    return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint32_t feat_keep_threshold(float keep) { return (uint32_t)(keep * 65536.0f); }
 

@@ -66,25 +66,44 @@ FEAT_SALT = 0x5DEECE66D
 
 
 def keep_mask_host(seed, idx, keep):
-    """Host twin of keep_mask in gat_amd/csrc/device_common.h (splitmix64 finaliser, top 24 bits)."""
+    """Host twin of keep_mask in gat_amd/csrc/device_common.h (32-bit mixer of the folded (seed, index) pair, top 24 bits)."""
+    idx = np.asarray(idx).astype(np.uint64)
+    seed = int(seed) & ((1 << 64) - 1)
+    m32 = np.uint64(0xFFFFFFFF)
     with np.errstate(over="ignore"):
-        z = idx.astype(np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    r = (z >> np.uint64(40)).astype(np.float32)
+        lo = (idx & m32) ^ np.uint64(seed & 0xFFFFFFFF)
+        hi = (idx >> np.uint64(32)) ^ np.uint64(seed >> 32)
+        x = (lo + hi * np.uint64(0x9E3779B9)) & m32
+        x ^= x >> np.uint64(16)
+        x = (x * np.uint64(0x7FEB352D)) & m32
+        x ^= x >> np.uint64(15)
+        x = (x * np.uint64(0x846CA68B)) & m32
+        x ^= x >> np.uint64(16)
+    r = (x >> np.uint64(8)).astype(np.float32)
     return (r * np.float32(1.0 / 16777216.0)) < np.float32(keep)
+
+
+def _mix32(x):
+    m32 = np.uint64(0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        x = x ^ (x >> np.uint64(16))
+        x = (x * np.uint64(0x7FEB352D)) & m32
+        x = x ^ (x >> np.uint64(15))
+        x = (x * np.uint64(0x846CA68B)) & m32
+        return x ^ (x >> np.uint64(16))
 
 
 def feat_keep_host(seed, elem, keep):
     """Host twin of drop_feat / drop_feat1 in gat_amd/csrc/device_common.h: element index e of the [rows, hd]
-    table belongs to group e >> 2, one splitmix64 per group, 16 bits per element against keep * 65536."""
+    table belongs to group e >> 2, 64 mixed bits per group, 16 bits per element against keep * 65536."""
     elem = np.asarray(elem).astype(np.uint64)
+    s = (int(seed) ^ FEAT_SALT) & ((1 << 64) - 1)
+    m32 = np.uint64(0xFFFFFFFF)
+    group = elem >> np.uint64(2)
     with np.errstate(over="ignore"):
-        z = (elem >> np.uint64(2)) + (np.uint64(seed) ^ np.uint64(FEAT_SALT)) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
+        lo = _mix32((((group & m32) ^ np.uint64(s & 0xFFFFFFFF)) + ((group >> np.uint64(32)) ^ np.uint64(s >> 32)) * np.uint64(0x9E3779B9)) & m32)
+        hi = _mix32((lo + np.uint64(0x9E3779B9)) & m32)
+    z = (hi << np.uint64(32)) | lo
     field = (z >> (np.uint64(16) * (elem & np.uint64(3)))) & np.uint64(0xffff)
     return field < np.uint64(int(np.float32(keep) * np.float32(65536.0)))
 
