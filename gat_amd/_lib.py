@@ -52,6 +52,7 @@ _SIGNATURES = {
     "gatmi_gat_fwd_noalloc": (c_int, [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, c_int64, P, P, c_int32, c_int64, P, P, P, P, P, P,
                                       c_int32, c_int32, c_float, c_float, c_float, c_uint64, P, P, P, P, P, P]),
     "gatmi_dropout_step_source": (c_int, [P]),
+    "gatmi_dropout_step_source_current": (P, []),
     "gatmi_dropout_step_multiplier": (c_uint64, []),
     "gatmi_gat_bwd_node_ws_floats": (c_size_t, [c_int32, c_int32]),
     "gatmi_gat_bwd_node": (c_int, [c_int64, c_int32, c_int32, P, P, P, P, P, P, P, P, c_int32, c_int32, c_float,

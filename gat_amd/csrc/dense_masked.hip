@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "common.h"
 #include "device_common.h"
@@ -382,7 +383,24 @@ __device__ __forceinline__ void graph_fwd_batch(MRowState &st, float slope, cons
 }
 
 constexpr int kGraphFwdThreads = 1024;
-constexpr size_t kGraphFwdLdsMax = 160 * 1024;          // a workgroup may hold all of a CU's LDS
+// LDS one workgroup of the graph-resident kernels may ask for: what the current device grants a single
+// block (all 160 KB of a CU on gfx950), looked up once per device.  The gates below compare against it, so
+// that on a part with less LDS the shapes that do not fit go to the row-block kernels instead of failing
+// in hipFuncSetAttribute.
+static size_t graph_lds_limit() {
+    constexpr int kDevs = 64;
+    static std::atomic<size_t> cached[kDevs] = {};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevs) return 64 * 1024;
+    size_t v = cached[dev].load(std::memory_order_acquire);
+    if (v == 0) {
+        int bytes = 0;
+        if (hipDeviceGetAttribute(&bytes, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || bytes <= 0) bytes = 64 * 1024;
+        v = (size_t)bytes;
+        cached[dev].store(v, std::memory_order_release);
+    }
+    return v;
+}
 
 // list capacity per row: every column, plus one batch of padding, as whole batches
 static inline int graph_list_capacity(int N) { return (N + 2 * kGraphBatch - 1) / kGraphBatch * kGraphBatch; }
@@ -1495,7 +1513,7 @@ extern "C" int gatmi_dense_attn_fwd_masked(int64_t B, int32_t N, int32_t H, int3
     // many small graphs: one block per graph with the graph's rows resident in LDS
     const int lc = graph_list_capacity(N);
     if (!drop && G == 16 && LPH >= 2 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch &&
-        graph8_fwd_lds(N, H, lc, graph8_waves(N)) <= kGraphFwdLdsMax) {
+        graph8_fwd_lds(N, H, lc, graph8_waves(N)) <= graph_lds_limit()) {
         const int waves = graph8_waves(N);
         const size_t lds = graph8_fwd_lds(N, H, lc, waves);
         hipError_t e = hipSuccess;
@@ -1515,7 +1533,7 @@ extern "C" int gatmi_dense_attn_fwd_masked(int64_t B, int32_t N, int32_t H, int3
         X(1) X(2) X(4) X(8)
 #undef X
     }
-    if (!drop && G == 16 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && graph_fwd_lds(N, G, H, lc) <= kGraphFwdLdsMax) {
+    if (!drop && G == 16 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && graph_fwd_lds(N, G, H, lc) <= graph_lds_limit()) {
         const size_t lds = graph_fwd_lds(N, G, H, lc);
         hipError_t e = hipSuccess;
 #define X(ll)                                                                                                      \
@@ -1571,7 +1589,7 @@ extern "C" int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int3
     // many small graphs: one block per graph with the graph's rows resident in LDS
     const int lcg = graph_list_capacity(N);
     if (!drop && G == 16 && LPH >= 2 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch &&
-        graph8_bwd_lds(N, H, lcg, graph8_waves(N)) <= kGraphFwdLdsMax) {
+        graph8_bwd_lds(N, H, lcg, graph8_waves(N)) <= graph_lds_limit()) {
         const int waves = graph8_waves(N);
         const size_t glds = graph8_bwd_lds(N, H, lcg, waves);
         hipError_t e = hipSuccess;
@@ -1586,7 +1604,7 @@ extern "C" int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int3
         X(1) X(2) X(4) X(8)
 #undef X
     }
-    if (!drop && G == 16 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && graph_bwd_lds(N, H, lcg) <= kGraphFwdLdsMax) {
+    if (!drop && G == 16 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && graph_bwd_lds(N, H, lcg) <= graph_lds_limit()) {
         const size_t glds = graph_bwd_lds(N, H, lcg);
         hipError_t e = hipSuccess;
 #define X(ll)                                                                                                      \
@@ -1621,7 +1639,7 @@ extern "C" int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int3
 static bool graph_fused_shape(int64_t B, int32_t N, int G, int LPH, int H, float coef_keep, float feat_keep) {
     const bool drop = coef_keep < 1.f || feat_keep < 1.f;
     return !drop && G == 16 && LPH >= 2 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && B <= 0x7fffffff &&
-           graph8_bwd_lds(N, H, graph_list_capacity(N), graph8_waves(N)) <= kGraphFwdLdsMax;
+           graph8_bwd_lds(N, H, graph_list_capacity(N), graph8_waves(N)) <= graph_lds_limit();
 }
 
 extern "C" int gatmi_dense_attn_bwd_fused_ok(int64_t B, int32_t N, int32_t H, int32_t dp, float coef_keep, float feat_keep) {

@@ -108,10 +108,23 @@ constexpr uint64_t kFeatSeedSalt = 0x5DEECE66Dull;
 // uses seed + word * kSeedStepMul.  The odd multiplier keeps (seed + small head-group offset, step)
 // pairs apart.  nullptr: the seed as passed.  A uniform read-only load: the compiler issues it as a
 // scalar load once per use site.
+//
+// The (stepped) seed then goes through the splitmix64 finaliser before any mask is drawn from it.
+// keep_mask / feat_group_bits fold the seed into the index by XOR, so two RAW seeds that differ in a
+// few low bits (seed + head group, seed = epoch) would give masks that are XOR-permutations of each
+// other's index space; after the finaliser neighbouring seeds share no such structure.  All of it is
+// uniform arithmetic on kernel arguments: scalar instructions, once per kernel.
 constexpr uint64_t kSeedStepMul = 0xD1B54A32D192ED03ull;
+__host__ __device__ __forceinline__ uint64_t scramble_seed(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
 template <class Args>
 __device__ __forceinline__ uint64_t seed_now(const Args &a) {
-    return a.seed_step ? a.seed + *a.seed_step * kSeedStepMul : a.seed;
+    return scramble_seed(a.seed_step ? a.seed + *a.seed_step * kSeedStepMul : a.seed);
 }
 
 // Feature dropout (utils/layers.py:22): ONE hash serves four consecutive elements of the [rows, hd] table,

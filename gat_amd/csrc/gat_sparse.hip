@@ -865,8 +865,10 @@ extern "C" int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
                                      const float *bias, const float *resid, int32_t activation, int32_t reduce,
                                      float slope, float coef_keep, float feat_keep, uint64_t seed,
                                      float *out, float *agg, float *pos, float *lse, float *q, void *stream) {
-    GATMI_REQUIRE(n_slots >= 0 && (n_split == 0) == (n_slots == 0), GATMI_EINVAL,
-                  "gat_fwd_noalloc: n_slots=%lld with n_split=%lld (both come from gatmi_work_items_count)", (long long)n_slots, (long long)n_split);
+    // two-phase items (gatmi_work_items_phased) park rows in slots without a split record, so slots
+    // without split rows are fine; split rows without any slot are not
+    GATMI_REQUIRE(n_slots >= 0 && (n_split == 0 || n_slots > 0), GATMI_EINVAL,
+                  "gat_fwd_noalloc: n_slots=%lld with n_split=%lld (both come from gatmi_work_items_count or gatmi_work_items_phased_count)", (long long)n_slots, (long long)n_split);
     const size_t need = gatmi_gat_fwd_ws_floats(n_slots, H, dp);
     GATMI_REQUIRE(need <= kScratchFloats, GATMI_ERANGE,
                   "gat_fwd_noalloc: %lld partial-result slots need %zu bytes, the built-in store holds %zu; use gatmi_gat_fwd "
@@ -905,6 +907,12 @@ extern "C" int gatmi_dropout_step_source(const uint64_t *device_word) {
     const uint64_t *old = step_word_of_device[dev].exchange(device_word, std::memory_order_acq_rel);
     step_words_registered.fetch_add((device_word ? 1 : 0) - (old ? 1 : 0), std::memory_order_acq_rel);
     return GATMI_OK;
+}
+
+extern "C" const uint64_t *gatmi_dropout_step_source_current(void) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    return step_word_of_device[dev].load(std::memory_order_acquire);
 }
 
 extern "C" uint64_t gatmi_dropout_step_multiplier(void) { return kSeedStepMul; }

@@ -22,16 +22,20 @@ def stepped_seed(seed, step):
 
 @contextlib.contextmanager
 def dropout_step_word(word):
-    """While the block runs, every dropout launch issued on the current device carries the address of
-    `word` (a one-element int64 tensor on that device) and reads it when the kernel runs."""
+    """While the block runs, every dropout launch issued on `word`'s device — from any thread or
+    stream: the registration is device-wide — carries the address of `word` (a one-element int64 tensor
+    on that device) and reads it when the kernel runs.  On exit the word that was registered before
+    (an enclosing scope's, or none) is put back."""
     if word.dtype != torch.int64 or word.numel() != 1 or not word.is_cuda:
         raise ValueError("the step word is a one-element int64 tensor on the GPU")
     with torch.cuda.device(word.device):
+        before = _lib.lib.gatmi_dropout_step_source_current()
         _lib.call("gatmi_dropout_step_source", word.data_ptr())
         try:
             yield word
         finally:
-            _lib.call("gatmi_dropout_step_source", None)
+            with torch.cuda.device(word.device):
+                _lib.call("gatmi_dropout_step_source", before)
 
 
 def capture(step, warmup=3, fresh_dropout=True):

@@ -221,8 +221,9 @@ int gatmi_gat_fwd(int64_t n_dst, int32_t H, int32_t dp,
  * workspace of gatmi_gat_fwd.  It has NO counterpart in the reference.  The partial results of split
  * rows go to a fixed store of GATMI_NOALLOC_SCRATCH_BYTES inside the library's code object (one copy
  * per GPU, held until the process ends) instead of `ws`; everything else, and every result bit, is as
- * in gatmi_gat_fwd.  n_slots is the slot count gatmi_work_items_count reported for these items
- * (0 when no row is split); the call fails with GATMI_ERANGE when
+ * in gatmi_gat_fwd.  n_slots is the slot count gatmi_work_items_count (or, for two-phase items,
+ * gatmi_work_items_phased_count, whose parked rows take slots without a split record) reported for
+ * these items (0 when no row is split or parked); the call fails with GATMI_ERANGE when
  * gatmi_gat_fwd_ws_floats(n_slots, H, dp) * 4 exceeds the store (13 797 slots at H = 8, dp = 8).
  * The function calls no hipMalloc / hipFree and no allocating routine.  Its first call on a device
  * looks up that device's address of the store (hipGetSymbolAddress): make that first call outside
@@ -249,8 +250,13 @@ int gatmi_gat_fwd_noalloc(int64_t n_dst, int32_t H, int32_t dp,
  * step draws fresh masks; forward and backward launches of one step must see the same value.
  * word = NULL ends it for later launches; launches already captured keep reading the word they were
  * captured with, which must stay allocated for as long as they can run.  With no word registered the
- * masks are exactly those of the seed passed (bit-identical to a library without this call). */
+ * masks are exactly those of the seed passed (bit-identical to a library without this call).
+ * The registration is DEVICE-WIDE (one word per device for the whole process: autograd issues the
+ * backward launches from a thread of its own): while it stands, dropout launches from every thread and
+ * stream on that device carry the word.  gatmi_dropout_step_source_current() returns the word
+ * registered for the current device (NULL: none), so that a scope can put back what it found. */
 int gatmi_dropout_step_source(const uint64_t *device_word);
+const uint64_t *gatmi_dropout_step_source_current(void);
 uint64_t gatmi_dropout_step_multiplier(void);
 
 /* Backward, per-destination part (no gather).  From dOut and the saved forward tensors:

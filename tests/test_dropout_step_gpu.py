@@ -151,6 +151,27 @@ def test_capture_without_fresh_dropout_replays_one_set_of_masks():
         assert torch.equal(a, b) and torch.equal(a, c)
 
 
+def test_nested_scopes_put_back_the_outer_word():
+    from gat_amd import _lib, graphs
+    outer = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    inner = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    cur = _lib.lib.gatmi_dropout_step_source_current
+    assert cur() is None
+    with graphs.dropout_step_word(outer):
+        assert cur() == outer.data_ptr()
+        with graphs.dropout_step_word(inner):
+            assert cur() == inner.data_ptr()
+        assert cur() == outer.data_ptr(), "leaving the inner scope dropped the outer scope's word"
+        run = _sparse_runner("f32")
+        outer.fill_(2)
+        at2 = run(SEED)
+    assert cur() is None
+    by_seed2 = run(graphs.stepped_seed(SEED, 2))
+    torch.cuda.synchronize()
+    for a, b in zip(at2, by_seed2):
+        assert torch.equal(a, b)
+
+
 def test_step_source_rejects_a_misaligned_word():
     from gat_amd import _lib
     word = torch.zeros(2, dtype=torch.int64, device="cuda:0")

@@ -93,3 +93,47 @@ def test_noalloc_forward_rejects_sizes_beyond_its_store():
     rc = _call("gatmi_gat_fwd_noalloc", graph, cfg, Wh, f1, f2, bias, outs, n_slots=1)
     torch.cuda.synchronize()
     assert rc == 0
+
+
+def test_noalloc_forward_takes_two_phase_items_whose_slots_have_no_split_record():
+    """gatmi_work_items_phased parks every row that has entries in both phases in a slot; a row with one piece
+    per phase gets a slot but no split record, so a shard can hold slots and no split rows at all."""
+    from gat_amd import _lib
+    from gat_amd._lib import ptr
+    dev = torch.device("cuda:0")
+    n, H = 240, 8
+    graph, cfg, Wh, f1, f2, bias = _inputs(n, 12, H, 8, seed=21, hubs=0, hub_deg=0, chunk=256, dev=dev)
+    rowptr = graph.rowptr_host
+    cut = np.ascontiguousarray(rowptr[:-1] + np.diff(rowptr) // 2, dtype=np.int64)
+    na, nb, ns, nl = (ctypes.c_int64() for _ in range(4))
+    _lib.call("gatmi_work_items_phased_count", n, ptr(rowptr), ptr(cut), graph.chunk, ctypes.byref(na), ctypes.byref(nb),
+              ctypes.byref(ns), ctypes.byref(nl))
+    assert ns.value == 0 and nl.value > 0, "wanted slots without split records, got %d split rows / %d slots" % (ns.value, nl.value)
+    ia, ib = np.empty((na.value, 4), dtype=np.int32), np.empty((nb.value, 4), dtype=np.int32)
+    sp = np.empty((max(ns.value, 1), 4), dtype=np.int32)
+    _lib.call("gatmi_work_items_phased", n, ptr(rowptr), ptr(cut), graph.chunk, ptr(ia), ptr(ib), ptr(sp))
+    ia, ib = torch.from_numpy(ia).to(dev), torch.from_numpy(ib).to(dev)
+
+    def run(name, outs, ws):
+        for items in (ia, ib):
+            head = [n, H, cfg.dp, ptr(items), len(items), None, 0]
+            if name == "gatmi_gat_fwd_noalloc":
+                head.append(nl.value)
+            tail = [ptr(graph.col), ptr(Wh), _lib.DTYPE_F32, H * cfg.dp, ptr(f1), ptr(f2), None, None, ptr(bias), None, _lib.ACT_ELU,
+                    _lib.REDUCE_CONCAT, 0.2, 1.0, 1.0, 0] + [ptr(o) for o in outs]
+            if name == "gatmi_gat_fwd":
+                tail.append(ptr(ws))
+            tail.append(_lib.current_stream())
+            assert getattr(_lib.lib, name)(*(head + tail)) == 0, _lib.last_error()
+
+    ws = torch.empty(_lib.lib.gatmi_gat_fwd_ws_floats(nl.value, H, cfg.dp), dtype=torch.float32, device=dev)
+    want, got = _outputs(n, H, cfg.dp, dev, 7.0), _outputs(n, H, cfg.dp, dev, -7.0)
+    run("gatmi_gat_fwd", want, ws)
+    run("gatmi_gat_fwd_noalloc", got, None)
+    torch.cuda.synchronize()
+    whole = _outputs(n, H, cfg.dp, dev, 3.0)
+    assert _call("gatmi_gat_fwd", graph, cfg, Wh, f1, f2, bias, whole, ws=ws) == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    for a, b, c, name in zip(got, want, whole, ("out", "agg", "pos", "lse", "q")):
+        assert torch.equal(a, b), "%s differs between gat_fwd_noalloc and gat_fwd on two-phase items" % name
+        assert torch.allclose(a, c, rtol=1e-5, atol=1e-6), "%s: two sweeps differ from one" % name

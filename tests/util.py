@@ -63,12 +63,24 @@ def assert_close(got, ref, rtol=1e-5, atol_scale=2e-6, what=""):
 
 # ---- host twins of the in-kernel dropout masks ---------------------------------------------------
 FEAT_SALT = 0x5DEECE66D
+_M64 = (1 << 64) - 1
+
+
+def scramble_seed(seed):
+    """Host twin of scramble_seed in gat_amd/csrc/device_common.h: the splitmix64 finaliser every kernel applies
+    to its (stepped) seed before drawing masks from it."""
+    z = int(seed) & _M64
+    z ^= z >> 30
+    z = (z * 0xBF58476D1CE4E5B9) & _M64
+    z ^= z >> 27
+    z = (z * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
 
 
 def keep_mask_host(seed, idx, keep):
     """Host twin of keep_mask in gat_amd/csrc/device_common.h (32-bit mixer of the folded (seed, index) pair, top 24 bits)."""
     idx = np.asarray(idx).astype(np.uint64)
-    seed = int(seed) & ((1 << 64) - 1)
+    seed = scramble_seed(seed)
     m32 = np.uint64(0xFFFFFFFF)
     with np.errstate(over="ignore"):
         lo = (idx & m32) ^ np.uint64(seed & 0xFFFFFFFF)
@@ -97,7 +109,7 @@ def feat_keep_host(seed, elem, keep):
     """Host twin of drop_feat / drop_feat1 in gat_amd/csrc/device_common.h: element index e of the [rows, hd]
     table belongs to group e >> 2, 64 mixed bits per group, 16 bits per element against keep * 65536."""
     elem = np.asarray(elem).astype(np.uint64)
-    s = (int(seed) ^ FEAT_SALT) & ((1 << 64) - 1)
+    s = (scramble_seed(seed) ^ FEAT_SALT) & _M64
     m32 = np.uint64(0xFFFFFFFF)
     group = elem >> np.uint64(2)
     with np.errstate(over="ignore"):
