@@ -55,12 +55,22 @@ def parse():
                          "of the halo sources are fetched once at set-up and projected locally, a step communicates only the "
                          "all-reduce of the parameter gradients; both (default): exchange is the line's value, the replicate-mode step "
                          "is timed afterwards and reported beside it under 'replicate_mode'")
-    ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
-                    help="N > 1, exchange: run the all-to-alls on a communication stream beside the sweeps that do not need "
-                         "them (on), or exchanges and kernels in turn (off).  The overlap costs some kernel time (every row's "
-                         "softmax state is parked between the two sweeps) and hides at most the sweep over owned sources, so "
-                         "which is faster depends on the share of owned sources and on the links: auto (default) times three "
-                         "steps of each at set-up, outside the timed region, and keeps the faster")
+    ap.add_argument("--overlap", choices=["auto", "on", "pipeline", "two_phase", "off"], default="auto",
+                    help="N > 1, exchange.  off: one all-to-all per direction, exchanges and kernels in turn.  pipeline (= on): "
+                         "each direction as pairwise steps on a communication stream; a peer's rows travel while the next peer's "
+                         "are packed (forward) or while the next owner's halo columns are swept (backward).  two_phase: pipeline, "
+                         "and the forward sweep is cut into owned-source and halo-source phases (every row's softmax state is "
+                         "parked in between).  auto (default): a full leg (W warm-up + K timed steps) of off, then of pipeline, "
+                         "three trial steps of two_phase and a full leg of it only if those were the fastest yet; the line's "
+                         "value is the fastest full leg, all legs are reported under dist.legs")
+    ap.add_argument("--no-configs4", dest="configs4", action="store_false",
+                    help="N > 1, --workload products: skip the second part of the run, which times every rank's share of "
+                         "BASELINE.json configs[4] (12.5 M rows / 250 M edges + self-loops per rank) and reports it under 'configs4'")
+    ap.add_argument("--c4-nodes", type=int, default=0, help="override the configs4 part's node count per GPU (debug / rehearsal)")
+    ap.add_argument("--c4-edges", type=int, default=0, help="override the configs4 part's edge count per GPU (debug / rehearsal)")
+    ap.add_argument("--deadline", type=int, default=300,
+                    help="N > 1: seconds one leg may take before rank 0 prints the line with the legs measured so far and "
+                         "ends the run with a non-zero status (a collective that never completes)")
     ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
                     help="bf16: gathered tables in bf16 (2e-2 parity class); the headline is f32")
     return ap.parse_args()
@@ -234,6 +244,12 @@ def run_cora(args):
 
 RMAT2B_NODES_PER_GPU = 12_500_000      # configs[4]: 100 M nodes / 2 B edges row-partitioned over 8 GPUs
 RMAT2B_EDGES_PER_GPU = 250_000_000
+# one-GPU denominators of the configs[4] target, measured by hand on one MI355X (fp32, same seeds)
+CONFIGS4_DENOMINATORS = {
+    "share_alone_ms": 36.1, "share_alone_source": "python bench.py --workload rmat2b (one rank's 12.5 M rows / 262.5 M entries, no halo)",
+    "whole_graph_one_gpu_ms": 280.3, "whole_graph_one_gpu_edges_per_s": 7.49e9,
+    "whole_graph_source": "profiles/r02_c5_single_gpu.json (benchmarks/bench_c5_single.py: all eight shards' 100 M nodes / 2.1 G entries on one GPU)",
+    "target": "8 GPUs >= 6 x the one-GPU rate <=> <= 46.7 ms per step"}
 
 
 def timed_steps(step, args, world, dev, lib):
@@ -266,6 +282,283 @@ def timed_steps(step, args, world, dev, lib):
     return elapsed, prof.summary()
 
 
+class LineKeeper:
+    """Rank 0's JSON line, built leg by leg and printed exactly once, whatever happens afterwards: at the normal
+    end, or by a watchdog thread when a leg overruns its deadline (a collective that never completes, e.g. because
+    one rank failed inside a step while the others wait for it) — the legs measured until then are not lost.
+    The watchdog then ends the process with a non-zero status; the launcher takes the other ranks down."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.line, self.printed = rank, None, False
+        self.lock = threading.Lock()
+        self.deadline, self.stage = None, None
+        if rank == 0:
+            threading.Thread(target=self._watch, daemon=True).start()
+
+    def arm(self, stage, seconds):
+        self.stage, self.deadline = stage, time.monotonic() + seconds
+
+    def disarm(self):
+        self.deadline = None
+
+    def emit(self, extra=None):
+        with self.lock:
+            if self.printed or self.rank != 0 or self.line is None:
+                return
+            if extra:
+                self.line.update(extra)
+            print(json.dumps(self.line), flush=True)
+            self.printed = True
+
+    def _watch(self):
+        while True:
+            time.sleep(1.0)
+            d = self.deadline
+            if d is not None and time.monotonic() > d:
+                self.emit({"aborted_in": self.stage, "abort_reason": "the leg did not finish within its deadline; the line holds what was measured before it"})
+                sys.stdout.flush()
+                os._exit(3)
+
+
+def kernel_ms(ksum, steps):
+    return {k: v[0] * v[1] / steps for k, v in ksum.items()}       # ms per step of each entry point (all its launches)
+
+
+def build_line(args, world, storage, shape_name, workload, n_own, E_rank, E_total, ms_per_step, ksum, info, dist_info):
+    """The JSON line of one measured configuration (rank 0)."""
+    s_bytes = 4 if storage == "f32" else 2
+    per_step = kernel_ms(ksum, args.steps)
+    dom = max(per_step, key=per_step.get) if per_step else None
+    roofline = None
+    if dom:
+        ab = kernel_alg_bytes(dom, E_rank, n_own, s=s_bytes)
+        gbps = ab / (per_step[dom] * 1e-3) / 1e9
+        traffic, traffic_src = (None, "single-GPU figure only") if world > 1 else pmc_traffic(dom, storage, E_rank)
+        roofline = {"bound": "hbm", "kernel": dom, "kernel_symbol": KERNEL_SYMBOL.get(dom, {}).get(storage),
+                    "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "alg_bytes_per_launch": ab, "avg_ms": round(per_step[dom], 4),
+                    "launches_per_step": ksum[dom][1] // args.steps,
+                    "note": "achieved = algorithmic bytes / time: every entry is charged its full gather, so rows gathered "
+                            "many times (hubs) that L2 / Infinity Cache serve push it past what HBM itself delivers; "
+                            "traffic_* prices the bytes the counters saw leave L2"}
+        if traffic:
+            tg = traffic / (per_step[dom] * 1e-3) / 1e9
+            roofline["traffic_achieved"] = round(tg, 1)
+            roofline["traffic_frac"] = round(tg / HBM_PEAK_GBPS, 4)
+    lb = layer_alg_bytes(E_rank, n_own, s=s_bytes)
+    lg = lb / (ms_per_step * 1e-3) / 1e9
+    # compulsory lower bound: every array touched once, no gather counted (E index entries of 16 B + the per-node bytes)
+    b_min = E_rank * 16 + n_own * (8 * F_IN + 7 * HEADS * WIDTH * 4 + 12 * HEADS * 4 + 8)
+    impl = sum(kernel_alg_bytes(k, E_rank, n_own, s=s_bytes) for k in
+               ("gatmi_proj_fwd", "gatmi_gat_fwd", "gatmi_gat_bwd_node", "gatmi_gat_bwd_csc", "gatmi_proj_bwd_params"))
+    ig = impl / (ms_per_step * 1e-3) / 1e9
+    if world == 1:
+        partitioning = "single GPU"
+    elif dist_info["halo"] == "replicate":
+        partitioning = ("row-partitioned x%d, halo sources' input rows replicated at set-up and projected locally; per step one "
+                        "RCCL all-reduce of the parameter gradients" % world)
+    else:
+        how = {"off": "", "pipeline": ", as pairwise steps on a communication stream (a peer's rows travel while the next peer's are packed / swept)",
+               "two_phase": ", as pairwise steps on a communication stream, the forward sweep cut into owned-source and halo-source phases"}
+        partitioning = ("row-partitioned x%d, RCCL exchange of halo Wh rows (forward) and of their gradients (backward) every "
+                        "step%s, one all-reduce of the parameter gradients" % (world, how.get(dist_info["overlap"], "")))
+    return {
+        "metric": "GAT layer fwd+bwd edges/sec (8 heads) + % HBM roofline at 1/2/4/8 GPUs",
+        "value": E_total / (ms_per_step * 1e-3), "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if storage == "f32" else "f32 arithmetic, bf16 gather tables", "data": "synthetic",
+        "backend": dist_info["backend"] if dist_info else None,
+        "config": {"workload": "%s: %d nodes, %d edge entries (self-loops included), %d-d features, %d heads x %d, ELU, "
+                               "fwd+bwd of one layer" % (shape_name, n_own, E_rank, F_IN, HEADS, WIDTH),
+                   "name": workload, "partitioning": partitioning},
+        "roofline": roofline,
+        "layer_roofline": {"bound": "hbm", "alg_bytes": lb, "achieved": round(lg, 1), "peak": HBM_PEAK_GBPS,
+                           "unit": "GB/s", "frac": round(lg / HBM_PEAK_GBPS, 4),
+                           "note": "survey byte model (944 B/edge + 2984 B/node), the common yardstick; impl_* prices the bytes "
+                                   "this implementation's five kernels actually have to move",
+                           "impl_bytes": impl, "impl_achieved": round(ig, 1), "impl_frac": round(ig / HBM_PEAK_GBPS, 4),
+                           "b_min_bytes": b_min, "b_min_achieved": round(b_min / (ms_per_step * 1e-3) / 1e9, 1),
+                           "b_min_note": "compulsory lower bound (each array touched once, gathers not counted): what an "
+                                         "infinite cache would leave; the gap to impl_bytes is the gather traffic"},
+        "kernels_ms": {k: round(v, 4) for k, v in sorted(per_step.items())},
+        "info": info,
+    }
+
+
+SHAPES = {
+    "products": (None, None, "R-MAT power-law graph at ogbn-products shape per GPU"),
+    "rmat2b": (RMAT2B_NODES_PER_GPU, RMAT2B_EDGES_PER_GPU, "one eighth of the 100 M-node / 2 B-edge R-MAT graph per GPU"),
+}
+
+
+def run_shard_legs(args, leg_args, workload, n_own, e_own, rank, world, dev, backend, keeper, deadline_s):
+    """Every leg of one workload on this rank's shard.  Returns (legs, shard facts): legs maps a leg's name to
+    {"ms_per_step", "kernels", "comm"} or {"error"}.  A leg's outcome is agreed on by all ranks (one MAX
+    all-reduce of a failure flag after it), so that every rank goes on to the same next collective."""
+    import torch.distributed as dist
+    from gat_amd import _lib, dist as gdist
+    keeper.arm("set-up of the %s shard" % workload, deadline_s * 2)
+    bench = gdist.BenchShard(rank, world, n_own, e_own, F_IN, HEADS, WIDTH, dev, args.chunk, args.storage)
+    facts = {"E_rank": bench.E_rank, "info": bench.info(), "n_halo": bench.pg.n_halo, "n_send": bench.pg.exchange.n_send,
+             "local_entry_fraction": round(bench.pg.local_entries / max(1, bench.E_rank), 4)}
+    t = torch.tensor([float(bench.E_rank)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    facts["E_total"] = float(t[0])
+    legs = {}
+
+    def agreed_failure(local_error):
+        flag = torch.tensor([1.0 if local_error else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return float(flag[0]) > 0
+
+    def leg(name, halo, overlap, la):
+        keeper.arm("%s / %s" % (workload, name), deadline_s)
+        err = None
+        try:
+            step = bench.step_fn(halo, overlap=overlap)
+            bench.pg.exchange.enable_timing()
+            elapsed, ksum = timed_steps(step, la, world, dev, _lib)
+            torch.cuda.synchronize()
+            a2a_total_ms, sent, received, n_x = bench.pg.exchange.a2a_summary()
+            per = la.steps + la.warmup               # the exchange's events cover the warm-up steps too
+            res = {"ms_per_step": elapsed / la.steps * 1e3, "ksum": ksum, "steps": la.steps,
+                   "comm": {"exchange_ms": round(a2a_total_ms / per, 4), "exchanges_per_step": n_x // per,
+                            "bytes_sent_per_step": sent // per, "bytes_received_per_step": received // per}}
+        except Exception as exc:                     # noqa: BLE001 - a failed leg must not cost the line the legs that ran
+            err = "%s: %s" % (type(exc).__name__, exc)
+        if agreed_failure(err):
+            res = {"error": err or "failed on another rank"}
+        legs[name] = res
+        bench.release(halo)
+        return "error" not in res
+
+    want_exchange = args.halo in ("exchange", "both")
+    want_replicate = args.halo in ("replicate", "both")
+    if want_exchange:
+        ov = args.overlap
+        if ov in ("auto", "off"):
+            leg("exchange_sequential", "exchange", False, leg_args)            # one all-to-all per direction: the plainest form first
+        if ov in ("auto", "on", "pipeline"):
+            leg("exchange_pipeline", "exchange", "pipeline", leg_args)
+        if ov == "two_phase":
+            leg("exchange_two_phase", "exchange", "two_phase", leg_args)
+        elif ov == "auto" and "error" not in legs.get("exchange_pipeline", {"error": 1}):
+            # the two-phase forward sweep parks every row's state: it pays only when the links are slow and the share
+            # of owned sources is large, so it gets three trial steps and a full leg only if those are the fastest yet
+            trial = argparse.Namespace(warmup=2, steps=3)
+            if leg("exchange_two_phase_trial", "exchange", "two_phase", trial):
+                best = min(v["ms_per_step"] for k, v in legs.items() if k.startswith("exchange") and "error" not in v and "trial" not in k)
+                if legs["exchange_two_phase_trial"]["ms_per_step"] < best:
+                    leg("exchange_two_phase", "exchange", "two_phase", leg_args)
+    if want_replicate:
+        leg("replicate", "replicate", False, leg_args)
+    keeper.disarm()
+    del bench
+    torch.cuda.empty_cache()
+    return legs, facts
+
+
+def best_exchange(legs):
+    ok = {k: v for k, v in legs.items() if k.startswith("exchange") and "trial" not in k and "error" not in v}
+    return min(ok, key=lambda k: ok[k]["ms_per_step"]) if ok else None
+
+
+def legs_summary(legs):
+    out = {}
+    for k, v in legs.items():
+        out[k] = {"error": v["error"]} if "error" in v else dict(
+            v["comm"], ms_per_step=round(v["ms_per_step"], 4), steps=v["steps"],
+            kernels_ms={n: round(m, 4) for n, m in sorted(kernel_ms(v["ksum"], v["steps"]).items())})
+    return out
+
+
+def run_distributed(args, rank, world, local):
+    import datetime
+    import torch.distributed as dist
+    # GATMI_DIST_BACKEND=gloo rehearses N > 1 on a box with fewer GPUs than ranks (ranks share devices,
+    # buffers are staged through the host); the measured configuration is always nccl = RCCL.
+    backend = os.environ.get("GATMI_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend == "gloo" else local
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=args.deadline * 3))
+    else:
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=args.deadline * 3))
+    keeper = LineKeeper(rank)
+    name_of = {"exchange_sequential": "off", "exchange_pipeline": "pipeline", "exchange_two_phase": "two_phase"}
+    n_own, e_own, shape_name = SHAPES[args.workload]
+    from gat_amd import synth
+    n_own, e_own = args.nodes or n_own or synth.PRODUCTS_NODES, args.edges or e_own or synth.PRODUCTS_EDGES
+    rc = 0
+    legs, facts = run_shard_legs(args, args, args.workload, n_own, e_own, rank, world, dev, backend, keeper, args.deadline)
+    head = best_exchange(legs) if args.halo != "replicate" else None
+    if head is None and "error" not in legs.get("replicate", {"error": 1}):
+        head = "replicate"
+    if head is None:
+        if rank == 0:
+            print(json.dumps({"metric": "GAT layer fwd+bwd edges/sec (8 heads) + % HBM roofline at 1/2/4/8 GPUs", "value": None, "n_gpus": world,
+                              "error": "no leg completed", "legs": legs_summary(legs)}), flush=True)
+        dist.destroy_process_group()
+        raise SystemExit(2)
+    if rank == 0:
+        r = legs[head]
+        dist_info = dict(r["comm"], backend=("rccl" if backend == "nccl" else backend), world_size=world,
+                         halo="replicate" if head == "replicate" else "exchange", overlap=name_of.get(head),
+                         n_halo=facts["n_halo"], n_send=facts["n_send"], local_entry_fraction=facts["local_entry_fraction"],
+                         legs=legs_summary(legs),
+                         note="value = the fastest fully timed exchange-mode leg (every leg runs the same W warm-up + K timed steps)")
+        failed = [k for k, v in legs.items() if "error" in v]
+        if failed and args.halo != "replicate" and best_exchange(legs) is None:
+            dist_info["exchange_error"] = "; ".join("%s: %s" % (k, legs[k]["error"]) for k in failed if k.startswith("exchange"))
+        la = argparse.Namespace(steps=r["steps"], warmup=args.warmup)
+        line = build_line(la, world, args.storage, shape_name, args.workload, n_own, facts["E_rank"], facts["E_total"],
+                          r["ms_per_step"], r["ksum"], facts["info"], dist_info)
+        line["dist"] = dist_info
+        if "replicate" in legs and head != "replicate":
+            rp = legs["replicate"]
+            line["replicate_mode"] = {"error": rp["error"]} if "error" in rp else dict(
+                legs_summary({"replicate": rp})["replicate"], value=facts["E_total"] / (rp["ms_per_step"] * 1e-3))
+        keeper.line = line
+    if any("error" in v for v in legs.values()) and (args.halo == "replicate" or best_exchange(legs) is None):
+        rc = 4
+    # configs[4]: every rank's share of the 100 M-node / 2 B-edge graph, in the same process, so that the first
+    # multi-GPU line already carries the graph the scaling target is stated on
+    if args.workload == "products" and args.configs4 and (not (args.nodes or args.edges) or args.c4_nodes):
+        c4 = {"denominators_one_gpu": CONFIGS4_DENOMINATORS}
+        try:
+            la = argparse.Namespace(steps=min(args.steps, 10), warmup=min(args.warmup, 3))
+            n4, e4, name4 = SHAPES["rmat2b"]
+            n4, e4 = args.c4_nodes or n4, args.c4_edges or e4
+            legs4, facts4 = run_shard_legs(args, la, "rmat2b", n4, e4, rank, world, dev, backend, keeper, args.deadline)
+            c4.update(workload="%s: %d nodes, %d edge entries per rank" % (name4, n4, facts4["E_rank"]), world_size=world,
+                      n_halo=facts4["n_halo"], n_send=facts4["n_send"], local_entry_fraction=facts4["local_entry_fraction"],
+                      legs=legs_summary(legs4))
+            b4 = best_exchange(legs4)
+            for key, lname in (("exchange", b4), ("replicate", "replicate" if "error" not in legs4.get("replicate", {"error": 1}) else None)):
+                if lname:
+                    ms = legs4[lname]["ms_per_step"]
+                    c4[key] = {"leg": lname, "ms_per_step": round(ms, 4), "value": facts4["E_total"] / (ms * 1e-3), "unit": "edges/s",
+                               "vs_whole_graph_on_one_gpu": round(facts4["E_total"] / (ms * 1e-3) / CONFIGS4_DENOMINATORS["whole_graph_one_gpu_edges_per_s"], 3)
+                               if world == 8 else None}
+        except Exception as exc:                     # noqa: BLE001 - the products line stands whatever happens here
+            c4["error"] = "%s: %s" % (type(exc).__name__, exc)
+            rc = rc or 5
+        if rank == 0 and keeper.line is not None:
+            keeper.line["configs4"] = c4
+    keeper.disarm()
+    keeper.emit()
+    try:
+        dist.destroy_process_group()
+    except Exception:                                # noqa: BLE001
+        pass
+    if rc:
+        raise SystemExit(rc)
+
+
 def main():
     args = parse()
     if args.workload == "cora":
@@ -277,175 +570,40 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the graph-attention kernels have no CPU path")
-    # GATMI_DIST_BACKEND=gloo rehearses N > 1 on a box with fewer GPUs than ranks (ranks share devices,
-    # buffers are staged through the host); the measured configuration is always nccl = RCCL.
-    backend = os.environ.get("GATMI_DIST_BACKEND", "nccl")
-    local = local % torch.cuda.device_count() if backend == "gloo" else local
+    if world > 1:
+        return run_distributed(args, rank, world, local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    import gat_amd
+    import gat_amd  # noqa: F401
     from gat_amd import _lib, synth, CSRGraph
     from gat_amd.layers import GATHeads
 
-    if args.workload == "rmat2b":
-        n_own, e_own = RMAT2B_NODES_PER_GPU, RMAT2B_EDGES_PER_GPU
-        shape_name = "one eighth of the 100 M-node / 2 B-edge R-MAT graph per GPU"
-    else:
-        n_own, e_own = synth.PRODUCTS_NODES, synth.PRODUCTS_EDGES
-        shape_name = "R-MAT power-law graph at ogbn-products shape per GPU"
-    n_own = args.nodes or n_own
-    e_own = args.edges or e_own
-    chunk = args.chunk
+    n_own, e_own, shape_name = SHAPES[args.workload]
+    n_own, e_own = args.nodes or n_own or synth.PRODUCTS_NODES, args.edges or e_own or synth.PRODUCTS_EDGES
     storage = args.storage
-    dist_info = None
-    replicate_line = None
+    dst, src = synth.rmat_graph(n_own, e_own, 4, dev)
+    graph = CSRGraph.from_device_coo(dst, src, n_own, n_own, chunk=args.chunk)
+    del dst, src
+    E_rank = graph.nnz
+    x = synth.normal((n_own, F_IN), 5, dev)
+    dout = synth.normal((n_own, HEADS * WIDTH), 8, dev)
+    heads = GATHeads(F_IN, HEADS, WIDTH, device=dev, storage=storage)
+    heads.load(synth.glorot_layer(F_IN, HEADS, WIDTH, 7, dev))
+    heads.train()
+    params = list(heads.parameters())
 
-    if world > 1:
-        import torch.distributed as dist
-        from gat_amd import dist as gdist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-        bench = gdist.BenchShard(rank, world, n_own, e_own, F_IN, HEADS, WIDTH, dev, chunk, storage)
-        E_rank = bench.E_rank
-        info = bench.info()
-        modes = ["exchange", "replicate"] if args.halo == "both" else [args.halo]
-        results = {}
-        overlap, overlap_trial = args.overlap == "on", None
-        if args.overlap == "auto" and "exchange" in modes:
-            trial = argparse.Namespace(warmup=2, steps=3)
-            overlap_trial = {}
-            for ov in (True, False):
-                t_ov, _ = timed_steps(bench.step_fn("exchange", overlap=ov), trial, world, dev, _lib)     # max over ranks: same choice everywhere
-                overlap_trial["on" if ov else "off"] = round(t_ov / trial.steps * 1e3, 4)
-            overlap = overlap_trial["on"] <= overlap_trial["off"]
-        replicate_error = None
-        for mode in modes:
-            try:
-                step = bench.step_fn(mode, overlap=overlap)
-                bench.pg.exchange.enable_timing()
-                elapsed, ksum = timed_steps(step, args, world, dev, _lib)
-                torch.cuda.synchronize()
-                a2a_total_ms, sent, received, n_a2a = bench.pg.exchange.a2a_summary()
-                per_step = args.steps + args.warmup          # the exchange's events cover the warm-up steps too
-                results[mode] = (elapsed, ksum, {
-                    "a2a_ms": round(a2a_total_ms / per_step, 4), "a2a_per_step": n_a2a // per_step,
-                    "bytes_sent_per_step": sent // per_step, "bytes_received_per_step": received // per_step})
-                bench.release(mode)
-            except Exception as exc:          # the second leg of --halo both must not cost the line its measured value
-                if mode == modes[0]:
-                    raise
-                replicate_error = "%s: %s" % (type(exc).__name__, exc)
-        elapsed, ksum, comm = results[modes[0]]
-        dist_info = dict(comm, backend=("rccl" if backend == "nccl" else backend), world_size=dist.get_world_size(),
-                         halo=modes[0], overlap=(modes[0] == "exchange" and overlap), overlap_trial_ms=overlap_trial,
-                         n_halo=bench.pg.n_halo, n_send=bench.pg.exchange.n_send,
-                         local_entry_fraction=round(bench.pg.local_entries / max(1, E_rank), 4))
-        if len(modes) == 2 and "replicate" in results:
-            e2, k2, c2 = results["replicate"]
-            replicate_line = (e2, k2, c2)
-    else:
-        dst, src = synth.rmat_graph(n_own, e_own, 4, dev)
-        graph = CSRGraph.from_device_coo(dst, src, n_own, n_own, chunk=chunk)
-        del dst, src
-        E_rank = graph.nnz
-        x = synth.normal((n_own, F_IN), 5, dev)
-        dout = synth.normal((n_own, HEADS * WIDTH), 8, dev)
-        heads = GATHeads(F_IN, HEADS, WIDTH, device=dev, storage=storage)
-        heads.load(synth.glorot_layer(F_IN, HEADS, WIDTH, 7, dev))
-        heads.train()
-        params = list(heads.parameters())
-        info = {"graph": repr(graph)}
-
-        def layer_step():
-            for p in params:
-                p.grad = None
-            out = heads(x, graph, "elu", "concat")
-            out.backward(dout)
-        elapsed, ksum = timed_steps(layer_step, args, world, dev, _lib)
-
-    E_total = float(E_rank)
-    if world > 1:
-        t = torch.tensor([float(E_rank)], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
-        E_total = float(t[0])
-    ms_per_step = elapsed / args.steps * 1e3
-
-    if rank == 0:
-        s_bytes = 4 if storage == "f32" else 2
-        per_step = {k: v[0] * v[1] / args.steps for k, v in ksum.items()}       # ms per step of each entry point (all its launches)
-        dom = max(per_step, key=per_step.get) if per_step else None
-        roofline = None
-        if dom:
-            ab = kernel_alg_bytes(dom, E_rank, n_own, s=s_bytes)
-            gbps = ab / (per_step[dom] * 1e-3) / 1e9
-            traffic, traffic_src = (None, "single-GPU figure only") if world > 1 else pmc_traffic(dom, storage, E_rank)
-            roofline = {"bound": "hbm", "kernel": dom, "kernel_symbol": KERNEL_SYMBOL.get(dom, {}).get(storage),
-                        "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "alg_bytes_per_launch": ab, "avg_ms": round(per_step[dom], 4),
-                        "launches_per_step": ksum[dom][1] // args.steps,
-                        "note": "achieved = algorithmic bytes / time: every entry is charged its full gather, so rows gathered "
-                                "many times (hubs) that L2 / Infinity Cache serve push it past what HBM itself delivers; "
-                                "traffic_* prices the bytes the counters saw leave L2"}
-            if traffic:
-                tg = traffic / (per_step[dom] * 1e-3) / 1e9
-                roofline["traffic_achieved"] = round(tg, 1)
-                roofline["traffic_frac"] = round(tg / HBM_PEAK_GBPS, 4)
-        lb = layer_alg_bytes(E_rank, n_own, s=s_bytes)
-        lg = lb / (ms_per_step * 1e-3) / 1e9
-        # compulsory lower bound: every array touched once, no gather counted (E index entries of 16 B + the per-node bytes)
-        b_min = E_rank * 16 + n_own * (8 * F_IN + 7 * HEADS * WIDTH * 4 + 12 * HEADS * 4 + 8)
-        impl = sum(kernel_alg_bytes(k, E_rank, n_own, s=s_bytes) for k in
-                   ("gatmi_proj_fwd", "gatmi_gat_fwd", "gatmi_gat_bwd_node", "gatmi_gat_bwd_csc", "gatmi_proj_bwd_params"))
-        ig = impl / (ms_per_step * 1e-3) / 1e9
-        if world == 1:
-            partitioning = "single GPU"
-        elif dist_info["halo"] == "replicate":
-            partitioning = ("row-partitioned x%d, halo sources' input rows replicated at set-up and projected locally; per step one "
-                            "RCCL all-reduce of the parameter gradients" % world)
-        else:
-            partitioning = ("row-partitioned x%d, RCCL all-to-all of halo Wh rows (forward) and of their gradients (backward) every "
-                            "step%s, one all-reduce of the parameter gradients"
-                            % (world, ", on a communication stream beside the sweeps over owned sources / owned columns" if dist_info["overlap"] else ""))
-        line = {
-            "metric": "GAT layer fwd+bwd edges/sec (8 heads) + % HBM roofline at 1/2/4/8 GPUs",
-            "value": E_total / (ms_per_step * 1e-3), "unit": "edges/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if storage == "f32" else "f32 arithmetic, bf16 gather tables", "data": "synthetic",
-            "backend": dist_info["backend"] if dist_info else None,
-            "config": {"workload": "%s: %d nodes, %d edge entries (self-loops included), %d-d features, %d heads x %d, ELU, "
-                                   "fwd+bwd of one layer" % (shape_name, n_own, E_rank, F_IN, HEADS, WIDTH),
-                       "name": args.workload, "partitioning": partitioning},
-            "roofline": roofline,
-            "layer_roofline": {"bound": "hbm", "alg_bytes": lb, "achieved": round(lg, 1), "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": round(lg / HBM_PEAK_GBPS, 4),
-                               "note": "survey byte model (944 B/edge + 2984 B/node), the common yardstick; impl_* prices the bytes "
-                                       "this implementation's five kernels actually have to move",
-                               "impl_bytes": impl, "impl_achieved": round(ig, 1), "impl_frac": round(ig / HBM_PEAK_GBPS, 4),
-                               "b_min_bytes": b_min, "b_min_achieved": round(b_min / (ms_per_step * 1e-3) / 1e9, 1),
-                               "b_min_note": "compulsory lower bound (each array touched once, gathers not counted): what an "
-                                             "infinite cache would leave; the gap to impl_bytes is the gather traffic"},
-            "kernels_ms": {k: round(v, 4) for k, v in sorted(per_step.items())},
-            "info": info,
-        }
-        if dist_info:
-            line["dist"] = dist_info
-        if replicate_line:
-            e2, k2, c2 = replicate_line
-            ms2 = e2 / args.steps * 1e3
-            line["replicate_mode"] = dict(c2, ms_per_step=round(ms2, 4), value=E_total / (ms2 * 1e-3),
-                                          kernels_ms={k: round(v[0] * v[1] / args.steps, 4) for k, v in sorted(k2.items())})
-        elif world > 1 and replicate_error:
-            line["replicate_mode"] = {"error": replicate_error}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    def layer_step():
+        for p in params:
+            p.grad = None
+        out = heads(x, graph, "elu", "concat")
+        out.backward(dout)
+    elapsed, ksum = timed_steps(layer_step, args, 1, dev, _lib)
+    line = build_line(args, 1, storage, shape_name, args.workload, n_own, E_rank, float(E_rank), elapsed / args.steps * 1e3, ksum,
+                      {"graph": repr(graph)}, None)
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

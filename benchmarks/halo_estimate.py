@@ -36,13 +36,15 @@ class _NoPeers:
 
 
 class _LoopbackPeers(gdist.HaloExchange):
-    """HaloExchange whose peers are emulated on this GPU: as many rows leave as arrive, and an
-    all-to-all is a device-to-device copy of that size on the communication stream."""
+    """HaloExchange whose peers are emulated on this GPU: as many rows leave for a peer as arrive from it
+    (the real per-owner counts of this shard), and every transfer is a device-to-device copy of that size
+    on the communication stream."""
 
-    def __init__(self, n_own, n_halo, device):
-        self.rank, self.world, self.group, self.backend = 0, 2, None, "loopback"
+    def __init__(self, n_own, n_halo, device, counts):
+        self.rank, self.world, self.group, self.backend = 0, len(counts), None, "loopback"
         self.n_own, self.n_halo, self.device = n_own, n_halo, torch.device(device)
-        self.recv_counts, self.send_counts = [0, n_halo], [0, n_halo]
+        self.recv_counts, self.send_counts = [int(c) for c in counts], [int(c) for c in counts]
+        self._pool = torch.empty(max(int(max(counts)), 1) * 80, dtype=torch.float32, device=device)     # a peer's rows, either direction
         gen = torch.Generator(device=device)
         gen.manual_seed(11)
         reps = -(-n_halo // n_own)
@@ -51,6 +53,14 @@ class _LoopbackPeers(gdist.HaloExchange):
 
     def _a2a(self, out, inp, out_splits, in_splits):
         out.copy_(inp)
+
+    def _sendrecv(self, sends, to, recvs, frm):
+        for t in sends:
+            if t.numel():
+                self._pool.view(t.dtype)[:t.numel()].copy_(t.reshape(-1))
+        for t in recvs:
+            if t.numel():
+                t.copy_(self._pool.view(t.dtype)[:t.numel()].view(t.shape))
 
 
 def _kernel_breakdown(step, iters=5):
@@ -115,9 +125,9 @@ def main():
                 "exchange_MB_forward_f32": round(n_halo * 256 / 1e6), "exchange_MB_backward_f32": round(n_halo * 288 / 1e6), "replicated_input_MB": round(n_halo * F * 4 / 1e6),
                 "replicate_step_ms": round(ms, 3), "edges_per_s_per_gpu": round(g.nnz / ms * 1e3)}
         if world > 1:
-            pe = gdist.PartitionedGraph(g, _LoopbackPeers(n_own, n_halo, dev), part, 0)
+            pe = gdist.PartitionedGraph(g, _LoopbackPeers(n_own, n_halo, dev, counts), part, 0)
             xo = x[:n_own].contiguous()
-            for overlap in (True, False):
+            for overlap in ("two_phase", "pipeline", False):
                 def estep():
                     for p in params:
                         p.grad = None
@@ -129,9 +139,9 @@ def main():
                 for _ in range(10):
                     estep()
                 torch.cuda.synchronize()
-                line["exchange_step_ms_links_emulated_%s" % ("overlap" if overlap else "sequential")] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
-                if not overlap:
-                    line["exchange_sequential_kernels_ms"] = _kernel_breakdown(estep)
+                line["exchange_step_ms_links_emulated_%s" % (overlap or "sequential")] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
+                if overlap != "two_phase":
+                    line["exchange_%s_kernels_ms" % (overlap or "sequential")] = _kernel_breakdown(estep)
             line["two_phase_items"] = [len(pe.items_a), len(pe.items_b), len(pe.split_ab), pe.n_slots_ab]
             line["local_entry_frac"] = round(pe.local_entries / g.nnz, 3)
             del pe, xo

@@ -131,6 +131,10 @@ class HaloExchange:
 
     def _finish_setup(self):
         self.n_send = int(self.send_idx.numel())
+        # where peer p's rows sit: in the halo range (rows this rank reads, grouped by owner) and in the
+        # send list / the receive buffer of the reverse exchange (rows peers read here, grouped by reader)
+        self.recv_off = [0] + np.cumsum(self.recv_counts).tolist()
+        self.send_off = [0] + np.cumsum(self.send_counts).tolist()
         # the send list inverted: for every owned row some peer reads, where its returned copies sit in
         # the receive buffer of the reverse exchange (rows sorted, copies in peer order)
         order = torch.argsort(self.send_idx, stable=True)
@@ -182,6 +186,12 @@ class HaloExchange:
         cs = self._comm()
         cs.wait_event(ready)
         with torch.cuda.stream(cs):
+            # Stream order this relies on: the nccl backend runs a collective on a stream of its own that first
+            # waits for the stream CURRENT at the call (cs: the inputs are ready there) and, when the call is
+            # synchronous or its work object is waited for, makes that same current stream wait for the
+            # collective.  `done`, recorded on cs afterwards, therefore lies behind the transfer.  Both hold only
+            # while cs is the current stream at the call, hence the assertion; _a2a waits for every work object.
+            assert torch.cuda.current_stream(self.device) == cs, "the exchange must be issued with the communication stream current"
             for out, inp in pairs:
                 if self.timings is not None:
                     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -194,21 +204,78 @@ class HaloExchange:
             done.record(cs)
         return _Pending(done, [t for pr in pairs for t in pr])
 
+    def peer_steps(self):
+        """[(to, frm)] for the world - 1 steps of a pairwise exchange: in step k every rank r sends to r + k and
+        receives from r - k, so each step is a perfect matching of senders and receivers and all links are busy."""
+        return [((self.rank + k) % self.world, (self.rank - k) % self.world) for k in range(1, self.world)]
+
+    def _sendrecv(self, sends, to, recvs, frm):
+        """One step of a pairwise exchange, issued on the current stream: every non-empty tensor of `sends` goes
+        to rank `to`, every non-empty tensor of `recvs` is filled by rank `frm` (both ends know the counts, so an
+        empty tensor is skipped by both).  nccl: one grouped launch (batch_isend_irecv); the current stream waits
+        for it.  gloo: staged through host memory, done on return."""
+        sends = [t for t in sends if t.numel()]
+        recvs = [t for t in recvs if t.numel()]
+        if not sends and not recvs:
+            return
+        raw = lambda t: t.view(torch.uint8) if t.dtype == torch.bfloat16 else t      # moved as bytes: not every backend knows bfloat16
+        stage = self.backend == "gloo" and any(t.is_cuda for t in sends + recvs)
+        if stage:
+            torch.cuda.current_stream(self.device).synchronize()
+            s_buf = [raw(t).cpu() for t in sends]
+            r_buf = [torch.empty(raw(t).shape, dtype=raw(t).dtype) for t in recvs]
+        else:
+            s_buf, r_buf = [raw(t) for t in sends], [raw(t) for t in recvs]
+        ops = [dist.P2POp(dist.isend, t, to, self.group) for t in s_buf] + [dist.P2POp(dist.irecv, t, frm, self.group) for t in r_buf]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if stage:
+            for t, h in zip(recvs, r_buf):
+                raw(t).copy_(h)
+
+    def _step_on_comm(self, ready, sends, to, recvs, frm):
+        """_sendrecv on the communication stream behind `ready` (device buffers) or at once (host buffers)."""
+        if ready is None:
+            self._sendrecv(sends, to, recvs, frm)
+            return
+        cs = self._comm()
+        cs.wait_event(ready)
+        with torch.cuda.stream(cs):
+            assert torch.cuda.current_stream(self.device) == cs
+            if self.timings is not None:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(cs)
+            self._sendrecv(sends, to, recvs, frm)
+            if self.timings is not None:
+                t1.record(cs)
+                self.timings.append((t0, t1, sum(t.numel() * t.element_size() for t in sends),
+                                     sum(t.numel() * t.element_size() for t in recvs)))
+
+    def _comm_done(self, keep, device_buffers):
+        """A _Pending behind everything issued on the communication stream so far."""
+        if not device_buffers:
+            return _Pending()
+        done = torch.cuda.Event()
+        done.record(self._comm())
+        return _Pending(done, keep)
+
     def _a2a(self, out, inp, out_splits, in_splits):
         """all_to_all_single (every rank calls it, also with nothing to send); buffers are staged
-        through the memory the backend works on: host for gloo, device for nccl (= RCCL)."""
+        through the memory the backend works on: host for gloo, device for nccl (= RCCL).  The work object is
+        waited for before returning: with nccl that orders the current stream behind the transfer (the host does
+        not block), with gloo the transfer is complete."""
         if inp.dtype == torch.bfloat16:          # moved as bytes (rows stay rows): not every backend knows bfloat16
             inp, out = inp.view(torch.uint8), out.view(torch.uint8)
         if self.backend == "gloo" and (inp.is_cuda or out.is_cuda):
             o = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group, async_op=True).wait()
             out.copy_(o)
         elif self.backend == "nccl" and not (inp.is_cuda and out.is_cuda):
             o = torch.empty(out.shape, dtype=out.dtype, device=self.device)
-            dist.all_to_all_single(o, inp.to(self.device), out_splits, in_splits, group=self.group)
+            dist.all_to_all_single(o, inp.to(self.device), out_splits, in_splits, group=self.group, async_op=True).wait()
             out.copy_(o)
         else:
-            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True).wait()
 
     def gather_halo_pack(self, tables):
         """tables: list of (table [n_own + n_halo, width], width) whose owned rows are valid.  Packs the
@@ -231,6 +298,58 @@ class HaloExchange:
             return _Pending()
         pairs, ready = ticket
         return self._exchange(pairs, self.recv_counts, self.send_counts, ready)
+
+    def gather_halo_pairwise(self, tables):
+        """The forward exchange as world - 1 pairwise steps instead of one all-to-all: the rows one peer asked for
+        are packed (current stream) and leave (communication stream) while the next peer's rows are being packed,
+        so only the first pack stands in front of the transfers.  tables as for gather_halo_pack; returns a
+        _Pending; until its wait() nothing may read the halo rows."""
+        if self.world == 1:
+            return _Pending()
+        keep, on_device = [], False
+        for to, frm in self.peer_steps():
+            s0, s1 = self.send_off[to], self.send_off[to + 1]
+            r0, r1 = self.n_own + self.recv_off[frm], self.n_own + self.recv_off[frm + 1]
+            sends, recvs = [], []
+            for table, width in tables:
+                send = torch.empty((s1 - s0, width), dtype=table.dtype, device=table.device)
+                if s1 > s0:
+                    _pack_rows(table, self.send_idx[s0:s1], s1 - s0, width, send)
+                sends.append(send)
+                recvs.append(table[r0:r1])
+                on_device = on_device or table.is_cuda
+            keep += sends
+            self._step_on_comm(self._mark([(None, sends[0])]) if on_device else None, sends, to, recvs, frm)
+        return self._comm_done(keep, on_device)
+
+    def scatter_add_halo_pairwise(self, tables, sweep_owner, wire_bf16=()):
+        """The reverse exchange as world - 1 pairwise steps, each started as soon as its rows are final:
+        sweep_owner(p) is called (current stream) to produce the halo rows owned by rank p in every table, then
+        those rows leave for p on the communication stream while sweep_owner of the next peer runs.  Returns
+        a _Pending whose .recvs hold the rows the peers returned (the layout scatter_finalize /
+        scatter_add_halo_finish expect: grouped by reader, in send-list order)."""
+        if self.world == 1:
+            return None
+        recvs_all, keep, on_device = [], [], False
+        for k, (table, width) in enumerate(tables):
+            dt = torch.bfloat16 if (k in wire_bf16 and table.is_cuda) else table.dtype
+            recvs_all.append(torch.empty((self.n_send, width), dtype=dt, device=table.device))
+            on_device = on_device or table.is_cuda
+        for to, frm in self.peer_steps():
+            sweep_owner(to)
+            h0, h1 = self.n_own + self.recv_off[to], self.n_own + self.recv_off[to + 1]
+            s0, s1 = self.send_off[frm], self.send_off[frm + 1]
+            sends = []
+            for k, (table, width) in enumerate(tables):
+                send = table[h0:h1]
+                if recvs_all[k].dtype != table.dtype:
+                    send = send.to(recvs_all[k].dtype)
+                sends.append(send)
+            keep += sends
+            self._step_on_comm(self._mark([(None, sends[0])]) if on_device else None, sends, to, [r[s0:s1] for r in recvs_all], frm)
+        pend = self._comm_done(keep + recvs_all, on_device)
+        pend.recvs = recvs_all
+        return pend
 
     def gather_halo(self, table, width):
         """table [n_own + n_halo, width]: owned rows valid; fills the halo rows from their owners."""
@@ -335,6 +454,15 @@ class PartitionedGraph:
         self.items_csc_own, self.items_csc_halo = g.items_csc[own].contiguous(), g.items_csc[~own].contiguous()
         own = g.split_csc[:, 0] < self.n_own
         self.split_csc_own, self.split_csc_halo = g.split_csc[own].contiguous(), g.split_csc[~own].contiguous()
+        # the halo columns once more, grouped by the rank that owns them (halo rows are sorted by global id, so an
+        # owner's columns are one range of local ids): the pairwise reverse exchange sweeps one owner's columns,
+        # sends their results on their way and goes on with the next owner's
+        ex = self.exchange
+        edges = torch.tensor([self.n_own + o for o in ex.recv_off[1:]], dtype=self.items_csc_halo.dtype, device=dev)
+        io = torch.bucketize(self.items_csc_halo[:, 0].contiguous(), edges, right=True)
+        so = torch.bucketize(self.split_csc_halo[:, 0].contiguous(), edges, right=True)
+        self.items_csc_by_owner = [self.items_csc_halo[io == p].contiguous() for p in range(ex.world)]
+        self.split_csc_by_owner = [self.split_csc_halo[so == p].contiguous() for p in range(ex.world)]
 
     @classmethod
     def from_global_csr(cls, rowptr, col, part, rank, world, device, chunk=DEFAULT_CHUNK, group=None):
@@ -384,6 +512,8 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         graph, ex = pgraph.graph, pgraph.exchange
         F = x.shape[1]
         n, n_src = graph.n_dst, graph.n_src
+        two_phase_fwd = overlap == "two_phase"
+        overlap = overlap not in (False, "off", None, 0)
         if replicate:
             if x.shape[0] != n_src:
                 raise ValueError("halo='replicate': x must hold owned + halo rows (%d, from replicate_rows), got %d"
@@ -414,11 +544,15 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             gtab, gdt = torch.empty((n_src, ldf), dtype=torch.bfloat16, device=x.device), _lib.DTYPE_BF16
         _lib.call("gatmi_proj_fwd", ptr(x), n_proj, F, x.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1.contiguous()),
                   ptr(b2c), H, dp, ptr(feat), ptr(gtab) if bf16 else None, ldf, ptr(f1), ptr(f2), None, None, None, st)
-        ticket = None
-        if not replicate:
+        ticket = pend_fwd = None
+        if not replicate and ex.world > 1:
             # fp32: only the Wh rows travel, the receiving sweep forms <Wh_j, a2> + b2 from them; bf16 rows
             # would add their rounding to the logits, so their records carry the exact f2 along
-            ticket = ex.gather_halo_pack([(gtab.view(torch.float32), ldf // 2)] if bf16 else [(feat, hd)])
+            travel = [(gtab.view(torch.float32), ldf // 2)] if bf16 else [(feat, hd)]
+            if overlap:
+                pend_fwd = ex.gather_halo_pairwise(travel)      # per peer: pack, send; the sweeps below run beside it
+            else:
+                ticket = ex.gather_halo_pack(travel)
 
         def widen_halo():
             # the per-source backward sweep reads its own Wh row and f2 in fp32: exact widening of what arrived
@@ -439,17 +573,19 @@ class DistSparseGATLayerFn(torch.autograd.Function):
                       ptr(graph.col), ptr(gtab), gdt, ldf, ptr(f1), *half, ptr(biasp), None,
                       ops._ACT[cfg.activation], ops._RED[cfg.reduce], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
                       ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws), st)
-        two_phase = ticket is not None and overlap and len(pgraph.items_a) and len(pgraph.items_b)
+        two_phase = pend_fwd is not None and two_phase_fwd and len(pgraph.items_a) and len(pgraph.items_b)
         if two_phase:
             ws = ops._new((max(1, _lib.lib.gatmi_gat_fwd_ws_floats(pgraph.n_slots_ab, H, dp)),), x)
             sweep(pgraph.items_a, pgraph.split_ab[:0], ws)       # entries reading owned rows, beside the exchange
-            ex.gather_halo_start(ticket).wait()
+            pend_fwd.wait()
             if bf16:
                 widen_halo()
             sweep(pgraph.items_b, pgraph.split_ab, ws)           # entries reading halo rows; merges rows cut further
         else:
             if ticket is not None:
-                ex.gather_halo_start(ticket).wait()
+                pend_fwd = ex.gather_halo_start(ticket)
+            if pend_fwd is not None:
+                pend_fwd.wait()
                 if bf16:
                     widen_halo()
             ws = None
@@ -524,13 +660,15 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         tables = [(dfeat, hd), (df2, H)]
         wire16 = (0,) if bf16 else ()        # bf16 storage: the returned dWh rows travel as bf16 too (df2 stays fp32: 32 B per row)
         if ctx.overlap and ex.world > 1:
-            sweep(pgraph.items_csc_halo, pgraph.split_csc_halo)      # the columns whose results travel
-            ticket = ex.scatter_add_halo_mark(tables, wire16)
-            sweep(pgraph.items_csc_own, pgraph.split_csc_own)        # owned columns, beside the exchange
+            # one owner's halo columns at a time: their results leave for the owner while the next owner's columns
+            # (and, behind the last owner, the owned columns) are swept
+            pend = ex.scatter_add_halo_pairwise(
+                tables, lambda p: sweep(pgraph.items_csc_by_owner[p], pgraph.split_csc_by_owner[p]), wire16)
+            sweep(pgraph.items_csc_own, pgraph.split_csc_own)
         else:
             sweep(graph.items_csc, graph.split_csc)
-            ticket = ex.scatter_add_halo_mark(tables, wire16)
-        ex.scatter_finalize(ex.scatter_add_halo_start(ticket), dfeat, df2, df1, a1p, a2p, H, dp)
+            pend = ex.scatter_add_halo_start(ex.scatter_add_halo_mark(tables, wire16))
+        ex.scatter_finalize(pend, dfeat, df2, df1, a1p, a2p, H, dp)
         dWh = dfeat[:n]
         dx, dW, da1, da2, db1, db2, _ = ops._project_backward(x, Wp, None, feat, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
         db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None
@@ -538,14 +676,22 @@ class DistSparseGATLayerFn(torch.autograd.Function):
 
 
 def dist_sparse_gat_layer(x, W, a1, a2, b1, b2, bias, pgraph, cfg, halo="exchange", overlap=True):
-    """halo="exchange": x [n_own, F], Wh / f2 rows of halo sources travel every step (any layer);
-    overlap=True runs the all-to-alls on a communication stream beside the sweeps that do not need
-    them (same results up to summation order), overlap=False runs exchange and kernels in turn.
+    """halo="exchange": x [n_own, F], Wh rows of halo sources travel every step (any layer).
+    overlap=False ("off"): one all-to-all per direction, exchanges and kernels in turn.
+    overlap=True ("pipeline"): each direction is world - 1 pairwise steps on a communication stream — forward,
+    a peer's rows leave while the next peer's are packed; backward, the halo columns are swept owner by owner and
+    an owner's results leave while the next owner's columns (last: the owned columns) are swept.  Same results
+    bit for bit as "off" (the kernels see the same lists in the same order per column).
+    overlap="two_phase": "pipeline", and the forward sweep is cut in two — entries that read owned rows run
+    beside the exchange, every row's softmax state is parked, a second launch takes it up over the entries that
+    read halo rows (same results up to summation order; pays only with slow links and a large owned share).
     halo="replicate": x [n_own + n_halo, F] from pgraph.replicate_rows (constant first-layer input):
     no communication besides the all-reduce of the parameter gradients."""
     if halo not in ("exchange", "replicate"):
         raise ValueError("halo must be 'exchange' or 'replicate'")
-    return DistSparseGATLayerFn.apply(x, W, a1, a2, b1, b2, bias, pgraph, cfg, halo == "replicate", bool(overlap))
+    if overlap not in (True, False, "off", "pipeline", "two_phase"):
+        raise ValueError("overlap must be False / 'off', True / 'pipeline' or 'two_phase'")
+    return DistSparseGATLayerFn.apply(x, W, a1, a2, b1, b2, bias, pgraph, cfg, halo == "replicate", overlap)
 
 
 def allreduce_grads(params, group=None):

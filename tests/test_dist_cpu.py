@@ -26,9 +26,31 @@ def _cpu_unpack_sum(recv, plan, width, table):
     table.index_add_(0, torch.repeat_interleave(rows, rptr[1:] - rptr[:-1]), recv[pos])
 
 
-def _worker(rank, world, port, n, seed, q):
+def _hub_graph(n, world, seed):
+    """A graph for the plan at the target world size (even blocks of n / world rows): one hub row in rank 0's
+    block read by every node of every other rank (its gradient comes back from all world - 1 peers), ranks
+    1 .. world-4 with random sources among blocks 0 .. world-4, rank world-3 reading nothing but the hub (empty
+    lists for every other peer), rank world-2 reading the last block only, the last rank reading block 1 only."""
+    rng = np.random.default_rng(seed)
+    blk = n // world
+    hub = 3
+    dst, src = [np.arange(n)], [np.arange(n)]
+    dst.append(np.arange(blk, n)); src.append(np.full(n - blk, hub))
+    lo_n = (world - 3) * blk
+    m = 4 * lo_n
+    dst.append(rng.integers(0, lo_n, m)); src.append(rng.integers(0, lo_n, m))
+    r6 = np.arange((world - 2) * blk, (world - 1) * blk)
+    dst.append(np.repeat(r6, 3)); src.append(rng.integers((world - 1) * blk, n, 3 * blk))
+    r7 = np.arange((world - 1) * blk, n)
+    dst.append(np.repeat(r7, 2)); src.append(rng.integers(blk, 2 * blk, 2 * blk))
+    key = np.unique(np.concatenate(dst).astype(np.int64) * n + np.concatenate(src))
+    return (key // n).astype(np.int32), (key % n).astype(np.int32)
+
+
+def _worker(rank, world, port, n, seed, kind, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         from gat_amd import dist as gdist, graph
@@ -37,14 +59,35 @@ def _worker(rank, world, port, n, seed, q):
         gdist._pack_rows, gdist._unpack_sum_rows = _cpu_pack, _cpu_unpack_sum
 
         F, H, D = 7, 2, 4
-        dst, src = random_graph(n, 4.0, seed, hubs=2, hub_deg=n // 2)
-        rowptr, col, _ = graph.csr_from_coo_host(n, dst, src)
-        part = gdist.partition_rows(n, world, rowptr, balance=1)
+        if kind == "hub":
+            dst, src = _hub_graph(n, world, seed)
+            rowptr, col, _ = graph.csr_from_coo_host(n, dst, src)
+            part = gdist.partition_rows(n, world)
+            assert (np.diff(part) == n // world).all()
+        else:
+            dst, src = random_graph(n, 4.0, seed, hubs=2, hub_deg=n // 2)
+            rowptr, col, _ = graph.csr_from_coo_host(n, dst, src)
+            part = gdist.partition_rows(n, world, rowptr, balance=1)
         lo, hi = int(part[rank]), int(part[rank + 1])
         cg = col[rowptr[lo]:rowptr[hi]].astype(np.int64)
         cl, halo, counts = gdist.halo_plan_host(part, rank, cg)
         ex = gdist.HaloExchange(rank, world, hi - lo, halo, counts, lo, "cpu")
         assert sum(ex.recv_counts) == len(halo)
+        if kind == "hub":
+            blk = n // world
+            if rank == 0:          # the hub row goes to every peer and comes back from every peer
+                assert all(c >= 1 for c in ex.send_counts[1:])
+                rows, rptr, _ = ex.unpack_plan
+                k = int((rows == 3).nonzero()[0])
+                assert int(rptr[k + 1] - rptr[k]) == world - 1
+                assert int(ex.row_ptr_all[4] - ex.row_ptr_all[3]) == world - 1
+            if rank == world - 3:  # reads the hub and nothing else: every other pair is empty in both directions' counts
+                assert ex.recv_counts == [1] + [0] * (world - 1) and list(halo) == [3]
+            if rank == world - 2:
+                assert [c > 0 for c in ex.recv_counts] == [True] + [False] * (world - 2) + [True]
+            if rank == world - 1:
+                assert ex.recv_counts[0] == 1 and ex.recv_counts[1] > 0 and sum(ex.recv_counts[2:]) == 0
+                assert ex.send_counts[world - 2] > 0 and sum(ex.send_counts[:world - 2]) == 0
 
         p = layer_params(F, H, D, seed=1)
         x = np.random.default_rng(2).normal(0, 1, (n, F))
@@ -76,6 +119,22 @@ def _worker(rank, world, port, n, seed, q):
             c2 = c2[(c2 < l2) | (c2 >= h2)]
             readers[c2] += 1
         assert (cnt[: hi - lo, 0].numpy() == readers[lo:hi]).all()
+
+        # the same two exchanges as world - 1 pairwise steps (the pipelined form of the layer)
+        ids2 = torch.zeros_like(ids)
+        ids2[: hi - lo] = ids[: hi - lo]
+        ex.gather_halo_pairwise([(ids2, 1)]).wait()
+        assert torch.equal(ids2, ids)
+        cnt2 = torch.zeros((hi - lo + len(halo), 1), dtype=torch.float64)
+        swept = []
+
+        def sweep_owner(p_):                     # the layer's per-owner sweep: here it just fills that owner's halo rows
+            swept.append(p_)
+            cnt2[hi - lo + ex.recv_off[p_]: hi - lo + ex.recv_off[p_ + 1]] = 1.0
+        pend = ex.scatter_add_halo_pairwise([(cnt2, 1)], sweep_owner)
+        ex.scatter_add_halo_finish(pend, [(cnt2, 1)])
+        assert sorted(swept) == [r for r in range(world) if r != rank] and swept[0] == (rank + 1) % world
+        assert torch.equal(cnt2[: hi - lo], cnt[: hi - lo])
 
         # end to end with autograd through a differentiable twin of the exchange
         class Gather(torch.autograd.Function):
@@ -152,7 +211,14 @@ def _worker(rank, world, port, n, seed, q):
 @pytest.mark.parametrize("world,n,seed", [(2, 61, 0), (2, 200, 1), (3, 97, 2)])
 def test_partitioned_layer_equals_single_graph(world, n, seed):
     from tests.util import run_ranks
-    run_ranks(_worker, world, (n, seed), timeout=240)
+    run_ranks(_worker, world, (n, seed, "random"), timeout=240)
+
+
+def test_partitioned_layer_at_world_eight_with_empty_pairs_and_a_row_every_peer_returns():
+    """The plan at the target world size: peer pairs that exchange nothing, a rank whose whole halo is one row,
+    and a row whose gradient comes back from all seven peers (fixed-order sum at the owner)."""
+    from tests.util import run_ranks
+    run_ranks(_worker, 8, (384, 5, "hub"), timeout=400)
 
 
 def test_device_and_host_halo_plans_agree_on_cpu_tensors():

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, light, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
@@ -52,16 +52,31 @@ def _worker(rank, world, port, q):
         assert_close(xd.grad.cpu().numpy(), xs.grad.cpu().numpy()[lo:hi], rtol=1e-5, atol_scale=2e-6, what="dX")
         for k in p:
             assert_close(dp_[k].grad.cpu().numpy(), tp[k].grad.cpu().numpy(), rtol=1e-5, atol_scale=5e-6, what="d" + k)
-        # the same without overlap (exchange and kernels in turn, one sweep per direction): same sums in another order
+        # the default is the pairwise pipeline.  Without overlap (one all-to-all per direction, exchange and kernels
+        # in turn) every kernel sees the same lists in the same order: bit-identical.  With the two-phase forward
+        # sweep the sums run in another order.
         assert len(pg.items_a) and len(pg.items_b) and pg.n_slots_ab > 0 and len(pg.items_csc_halo) >= pg.n_halo > 0
-        s_ = leaves()
-        xq = torch.tensor(x[lo:hi], device=dev, requires_grad=True)
-        oseq = gdist.dist_sparse_gat_layer(xq, s_["W"], s_["a1"], s_["a2"], s_["b1"], s_["b2"], s_["bias"], pg, cfg, overlap=False)
-        oseq.backward(torch.tensor(dout[lo:hi], device=dev))
-        gdist.allreduce_grads(list(s_.values()))
-        assert_close(oseq.detach().cpu().numpy(), out.detach().cpu().numpy(), rtol=2e-6, atol_scale=1e-6, what="overlap vs sequential out")
-        assert_close(xq.grad.cpu().numpy(), xd.grad.cpu().numpy(), rtol=1e-5, atol_scale=2e-6, what="overlap vs sequential dX")
-        assert_close(s_["W"].grad.cpu().numpy(), dp_["W"].grad.cpu().numpy(), rtol=1e-5, atol_scale=5e-6, what="overlap vs sequential dW")
+        assert sum(len(t) for t in pg.items_csc_by_owner) == len(pg.items_csc_halo) and len(pg.items_csc_by_owner[rank]) == 0
+        assert sum(len(t) for t in pg.split_csc_by_owner) == len(pg.split_csc_halo)
+        for ov in (False, "two_phase"):
+            s_ = leaves()
+            xq = torch.tensor(x[lo:hi], device=dev, requires_grad=True)
+            oseq = gdist.dist_sparse_gat_layer(xq, s_["W"], s_["a1"], s_["a2"], s_["b1"], s_["b2"], s_["bias"], pg, cfg, overlap=ov)
+            oseq.backward(torch.tensor(dout[lo:hi], device=dev))
+            gdist.allreduce_grads(list(s_.values()))
+            torch.cuda.synchronize()
+            if ov is False:
+                assert torch.equal(oseq, out) and torch.equal(xq.grad, xd.grad), "pipelined and sequential exchange differ"
+                for k in p:
+                    assert torch.equal(s_[k].grad, dp_[k].grad), "pipelined vs sequential d" + k
+            else:
+                assert_close(oseq.detach().cpu().numpy(), ref.detach().cpu().numpy()[lo:hi], rtol=2e-6, atol_scale=1e-6, what="two-phase out")
+                assert_close(xq.grad.cpu().numpy(), xs.grad.cpu().numpy()[lo:hi], rtol=1e-5, atol_scale=2e-6, what="two-phase dX")
+                for k in p:
+                    assert_close(s_[k].grad.cpu().numpy(), tp[k].grad.cpu().numpy(), rtol=1e-5, atol_scale=5e-6, what="two-phase d" + k)
+        if light:
+            q.put((rank, "ok"))
+            return
         # first-layer mode: halo sources' input rows replicated once, no exchange inside the step
         r_ = leaves()
         xr = pg.replicate_rows(torch.tensor(x[lo:hi], device=dev))
@@ -139,7 +154,14 @@ def _worker(rank, world, port, q):
 
 def test_two_ranks_on_one_gpu_match_single_gpu():
     from tests.util import run_ranks
-    run_ranks(_worker, 2, timeout=300)
+    run_ranks(_worker, 2, (False,), timeout=300)
+
+
+def test_four_ranks_on_one_gpu_match_single_gpu():
+    """Four ranks in one process group on the one GPU: three pairwise steps per direction with distinct send and
+    receive partners (with two ranks they coincide), pipelined, sequential and two-phase, against the single-GPU layer."""
+    from tests.util import run_ranks
+    run_ranks(_worker, 4, (True,), timeout=300)
 
 
 def _nccl_worker(rank, world, port, q):
