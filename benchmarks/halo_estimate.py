@@ -27,6 +27,7 @@ class _NoPeers:
     """Stand-in for HaloExchange when the peers are not running: nothing to send or receive."""
     def __init__(self, n_own, n_halo):
         self.n_own, self.n_halo, self.n_send, self.world = n_own, n_halo, 0, 1
+        self.recv_off = [0, n_halo]
 
     def gather_halo(self, table, width):
         pass

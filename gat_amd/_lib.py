@@ -73,8 +73,14 @@ _SIGNATURES = {
                                             c_float, c_float, c_uint64, P, P, P]),
     "gatmi_dense_attn_bwd_fused_ok": (c_int, [c_int64, c_int32, c_int32, c_int32, c_float, c_float]),
     "gatmi_dense_attn_bwd_fused_ws_floats": (c_size_t, [c_int64, c_int32, c_int32]),
-    "gatmi_dense_attn_bwd_fused": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, P, P, c_int32, P, P, P, P, P, P, c_float,
-                                           P, P, P, P, P, P, P]),
+    "gatmi_dense_attn_bwd_fused": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, P, P, c_int32, P, P, P, P,
+                                           P, P, P, c_int64, P, P, c_float, c_float, c_float, c_uint64, P, P, P, P, P, P, P]),
+    "gatmi_dense_mask_bits": (c_int, [c_int64, c_int32, P, c_float, P, P]),
+    "gatmi_dense_lists_count": (c_int, [c_int64, c_int32, P, P, P, P]),
+    "gatmi_dense_lists_fill": (c_int, [c_int64, c_int32, P, P, P, P, P, P]),
+    "gatmi_dense_lists_capacity": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    "gatmi_dense_attn_fwd_lists": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, c_int64, P, P, c_int32, c_float,
+                                           c_float, c_float, c_uint64, P, P, P, P, P, P]),
     "gatmi_bnf_attn_fwd": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, c_float, P, P, P, P, P, P]),
     "gatmi_bnf_attn_bwd_ws_floats": (c_size_t, [c_int64, c_int32, c_int32]),
     "gatmi_bnf_attn_bwd": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, P, c_float, P, P, P, P, P, P]),

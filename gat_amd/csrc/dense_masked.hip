@@ -48,6 +48,12 @@ struct MaskedFwdArgs {
     float slope, coef_keep, feat_keep;
     uint64_t seed;
     const uint64_t *seed_step;   // device word added to the seed at run time (seed_now), or nullptr
+    // prebuilt lists of a mask that does not change from step to step (dense_graph_fwd8_kernel<.., LISTS>):
+    // row r of graph b visits columns lcol[lptr[b*N + r] .. lptr[b*N + r + 1]), padded to whole batches with the
+    // dummy id N; lord[b*N + k] = the graph's row with the k-th longest list
+    const int32_t *lptr;
+    const uint16_t *lcol, *lord;
+    int lcap;                  // list entries of one graph the kernel's LDS area holds
 };
 
 struct MRowState {
@@ -599,9 +605,13 @@ struct MRowState8 {
     float4 acc0, acc1, pos0, pos1;
 };
 
-template <int LPH8, bool SAVE, bool SOFT>
+// DROP: coefficient dropout (utils/layers.py:20) per (entry, head) from the counter hash; `cbase` is the hash index of
+// column 0 of this lane's (row, head), an entry's index is cbase + j * H.  Feature dropout (:22) needs nothing here:
+// the rows in LDS were dropped when they were staged.
+template <int LPH8, bool SAVE, bool SOFT, bool DROP>
 __device__ __forceinline__ void graph_fwd_batch8(MRowState8 &st, float slope, const uint16_t *lp, const float *bm, int N,
-                                                 const float *whs, const float *f2s, float f1v) {
+                                                 const float *whs, const float *f2s, float f1v,
+                                                 uint64_t seed, uint64_t cbase, float coef_keep) {
     constexpr int H = 8 / LPH8;
     constexpr int HD = 64;
     constexpr int U = kGraphBatch;
@@ -626,15 +636,21 @@ __device__ __forceinline__ void graph_fwd_batch8(MRowState8 &st, float slope, co
     float bs = 0.f, bq = 0.f;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 bacc0 = zero, bacc1 = zero, bpos0 = zero, bpos1 = zero;
+    const float inv_keep = DROP ? 1.0f / coef_keep : 1.0f;
 #pragma unroll
     for (int t = 0; t < U; ++t) {
         const float p = exp_neg(e[t] - mn);
         bs += p;
-        bacc0 = f4_fma(p, v0[t], bacc0);
-        bacc1 = f4_fma(p, v1[t], bacc1);
+        float pa = p;
+        if (DROP) {
+            if (coef_keep < 1.f) pa = keep_mask(seed, cbase + (uint64_t)(uint32_t)j[t] * H, coef_keep) ? p * inv_keep : 0.f;
+        }
+        bacc0 = f4_fma(pa, v0[t], bacc0);
+        bacc1 = f4_fma(pa, v1[t], bacc1);
         if (SAVE) {
-            const float pp = z[t] > 0.f ? p : 0.f;
-            bq += pp;
+            const bool ps = z[t] > 0.f;
+            bq += ps ? p : 0.f;
+            const float pp = ps ? pa : 0.f;
             bpos0 = f4_fma(pp, v0[t], bpos0);
             bpos1 = f4_fma(pp, v1[t], bpos1);
         }
@@ -664,8 +680,30 @@ static inline size_t graph8_fwd_lds(int N, int H, int lc, int waves) {
     return (size_t)(N + kGraphPadRows) * (64 + H) * sizeof(float) + (size_t)waves * kGraphWalkRows * lc * sizeof(uint16_t) +
            (size_t)waves * kGraphWalkRows * sizeof(int);
 }
+// LDS with prebuilt lists: Wh | f2 | list offsets [N + 1 -> even] (int) | row order [N -> multiple of 4] (uint16) | `cap` list entries (uint16)
+static inline size_t graph8_lists_head_lds(int N) { return (size_t)((N + 2) & ~1) * sizeof(int) + (size_t)((N + 3) & ~3) * sizeof(uint16_t); }
+static inline size_t graph8_fwd_lists_lds(int N, int H, int cap) {
+    return (size_t)(N + kGraphPadRows) * (64 + H) * sizeof(float) + graph8_lists_head_lds(N) + (size_t)cap * sizeof(uint16_t);
+}
 
-template <int LPH8, bool SAVE>
+// Stage one graph's prebuilt lists: entries [ptr[b*N], ptr[(b+1)*N]) of `ids` (whole batches of four: 8-byte pieces),
+// the rows' offsets relative to the graph's first entry, and the graph's row order.  Offsets are clamped to `cap`, the
+// entries the LDS area holds, so a caller that understated its lists cannot make the block write or read past it.
+__device__ __forceinline__ void stage_graph_lists(int64_t b, int N, const int32_t *ptr, const uint16_t *ids, const uint16_t *ord, int cap,
+                                                  int *off_s, uint16_t *ord_s, uint16_t *ids_s) {
+    const int32_t base = ptr[b * N];
+    const int seg = min(ptr[(b + 1) * N] - base, cap & ~3);
+    const uint2 *src = reinterpret_cast<const uint2 *>(ids + base);
+    for (int e = threadIdx.x; e < seg / 4; e += blockDim.x) reinterpret_cast<uint2 *>(ids_s)[e] = src[e];
+    for (int r = threadIdx.x; r <= N; r += blockDim.x) off_s[r] = min(ptr[b * N + r] - base, seg);
+    for (int r = threadIdx.x; r < N; r += blockDim.x) ord_s[r] = ord[b * N + r];
+}
+
+// LISTS: the mask is not read at all; the lists come prebuilt (gatmi_dense_lists_fill) and are staged next to the
+// graph's rows, a wave takes the rows eight at a time in the order of their list lengths (rows of one octet finish
+// together), and what remains is the walk.  DROP: dropout of utils/layers.py:20,22 from the counter hashes, the
+// feature mask applied once per row while the graph is staged.
+template <int LPH8, bool SAVE, bool LISTS, bool DROP>
 __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_fwd8_kernel(MaskedFwdArgs a, int lc) {
     constexpr int G = 16;                  // compaction: lanes per row
     constexpr int H = 8 / LPH8;
@@ -679,23 +717,34 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_fwd8_kernel(
     const int64_t b = blockIdx.x;
     float *whs = reinterpret_cast<float *>(graph_smem);
     float *f2s = whs + NP * HD;
-    uint16_t *lists = reinterpret_cast<uint16_t *>(f2s + NP * H) + wave * kGraphWalkRows * lc;      // this wave's eight lists
+    // compaction mode: this wave's eight lists and their entry counts; lists mode: offsets, row order, all lists of the graph
+    uint16_t *lists = reinterpret_cast<uint16_t *>(f2s + NP * H) + (LISTS ? 0 : wave * kGraphWalkRows * lc);
     int *cnt = reinterpret_cast<int *>(reinterpret_cast<uint16_t *>(f2s + NP * H) + nwaves * kGraphWalkRows * lc) + wave * kGraphWalkRows;
-    const float *bmat = a.bias_mat + b * N * (int64_t)N;
+    int *off_s = reinterpret_cast<int *>(f2s + NP * H);
+    uint16_t *ord_s = reinterpret_cast<uint16_t *>(off_s + ((N + 2) & ~1));
+    if constexpr (LISTS) lists = ord_s + ((N + 3) & ~3);
+    const float *bmat = LISTS ? nullptr : a.bias_mat + b * N * (int64_t)N;
+    const uint64_t seed = DROP ? seed_now(a) : 0;
     // quads of this wave in order: (oct0, first half), (oct0, second half), (oct0 + nwaves * 8, first half), ...
     MaskRow next;
     int oct0 = wave * kGraphWalkRows;
-    load_mask_row(next, bmat + min(oct0 + grp, N - 1) * N, N, sub);
+    if constexpr (!LISTS) load_mask_row(next, bmat + min(oct0 + grp, N - 1) * N, N, sub);
     {
         const float4 *src = reinterpret_cast<const float4 *>(a.Wh + b * N * (int64_t)HD);
-        for (int e = threadIdx.x; e < NP * (HD / 4); e += blockDim.x)
-            reinterpret_cast<float4 *>(whs)[e] = e < N * (HD / 4) ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = threadIdx.x; e < NP * (HD / 4); e += blockDim.x) {
+            float4 v = e < N * (HD / 4) ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (DROP) {
+                if (a.feat_keep < 1.f) v = drop_feat(v, seed, b * N + (e >> 4), HD, (e & 15) * 4, a.feat_keep);
+            }
+            reinterpret_cast<float4 *>(whs)[e] = v;
+        }
         const float *src2 = a.f2 + b * N * (int64_t)H;
         for (int e = threadIdx.x; e < NP * H; e += blockDim.x) f2s[e] = e < N * H ? src2[e] : -INFINITY;
+        if constexpr (LISTS) stage_graph_lists(b, N, a.lptr, a.lcol, a.lord, a.lcap, off_s, ord_s, lists);
     }
     __syncthreads();
     const int W = (N + 31) / 32 + 1;
-    uint32_t *present_b = a.present ? a.present + b * N * (int64_t)W : nullptr;
+    uint32_t *present_b = (!LISTS && a.present) ? a.present + b * N * (int64_t)W : nullptr;
     // walk geometry: row r8 of the octet, lane s8 of the row
     const int r8 = lane >> 3, s8 = lane & 7;
     const int head8 = s8 / LPH8;
@@ -703,6 +752,7 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_fwd8_kernel(
     const float *f2l = f2s + head8;
     for (; oct0 < N; oct0 += nwaves * kGraphWalkRows) {
         bool anysoft = false;
+        if constexpr (!LISTS) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int row0 = oct0 + 4 * half;
@@ -766,26 +816,37 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_fwd8_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int i = min(oct0 + r8, N - 1);
+        }
         const bool row_ok = oct0 + r8 < N;
-        const int total = cnt[r8];
-        const uint16_t *lrow = lists + r8 * lc;
+        int i, total;
+        const uint16_t *lrow;
+        if constexpr (LISTS) {
+            i = ord_s[min(oct0 + r8, N - 1)];
+            const int o0 = off_s[i];
+            total = row_ok ? off_s[i + 1] - o0 : 0;
+            lrow = lists + o0;
+        } else {
+            i = min(oct0 + r8, N - 1);
+            total = cnt[r8];
+            lrow = lists + r8 * lc;
+        }
         const float f1v = a.f1[(b * N + i) * H + head8];
+        const uint64_t cbase = DROP ? ((uint64_t)(b * N + i) * (uint64_t)N) * H + head8 : 0;
         MRowState8 st;
         st.m = -INFINITY;
         st.s = st.q = 0.f;
         st.acc0 = st.acc1 = st.pos0 = st.pos1 = make_float4(0.f, 0.f, 0.f, 0.f);
         {
-            const float *bm_own = bmat + i * N;
-            if (anysoft) {                                // wave-uniform: biases are fetched for all of the wave's rows
+            const float *bm_own = LISTS ? nullptr : bmat + i * N;
+            if (!LISTS && anysoft) {                      // wave-uniform: biases are fetched for all of the wave's rows
                 for (int k = 0; k < total; k += kGraphBatch)
-                    graph_fwd_batch8<LPH8, SAVE, true>(st, a.slope, lrow + k, bm_own, N, whl, f2l, f1v);
+                    graph_fwd_batch8<LPH8, SAVE, !LISTS, DROP>(st, a.slope, lrow + k, bm_own, N, whl, f2l, f1v, seed, cbase, a.coef_keep);
             } else {
                 for (int k = 0; k < total; k += kGraphBatch)
-                    graph_fwd_batch8<LPH8, SAVE, false>(st, a.slope, lrow + k, bm_own, N, whl, f2l, f1v);
+                    graph_fwd_batch8<LPH8, SAVE, false, DROP>(st, a.slope, lrow + k, bm_own, N, whl, f2l, f1v, seed, cbase, a.coef_keep);
             }
         }
-        __builtin_amdgcn_wave_barrier();                 // every lane is done with the lists before the next rows overwrite them
+        if constexpr (!LISTS) __builtin_amdgcn_wave_barrier();   // every lane is done with the lists before the next rows overwrite them
         if (row_ok) {
             const int64_t row = b * N + i;
             const bool empty = !(st.s > 0.f);
@@ -846,6 +907,11 @@ struct MaskedBwdArgs {
     const float *dout, *out, *agg, *pos, *q, *f1, *lse, *bias;
     float *g_out, *df1_out, *dbias_ws;
     int activation;
+    // prebuilt lists (dense_graph_bwd8_kernel<.., LISTS>): column c of graph b is visited by rows
+    // lcol[lptr[b*N + c] .. lptr[b*N + c + 1]) (padded to whole batches with the dummy id N); lord = columns by list length
+    const int32_t *lptr;
+    const uint16_t *lcol, *lord;
+    int lcap;
 };
 
 struct MSrcState {
@@ -1185,9 +1251,12 @@ struct MSrcState8 {
     float df2;
 };
 
-template <int LPH8, bool SOFT>
+// DROP: coefficient dropout per (entry, head); `cbase` is the hash index of destination row 0 for this lane's
+// (column, head), an entry's index is cbase + i * (N * H).  wh0 / wh1 already carry the feature mask.
+template <int LPH8, bool SOFT, bool DROP>
 __device__ __forceinline__ void graph_bwd_batch8(MSrcState8 &st, float slope, const uint16_t *lp, const float *bmcol, int N,
-                                                 const float *gs, const float *ss, float f2v, float4 wh0, float4 wh1) {
+                                                 const float *gs, const float *ss, float f2v, float4 wh0, float4 wh1,
+                                                 uint64_t seed, uint64_t cbase, float coef_keep) {
     constexpr int H = 8 / LPH8;
     constexpr int HD = 64;
     constexpr int U = kGraphBatch;
@@ -1212,14 +1281,23 @@ __device__ __forceinline__ void graph_bwd_batch8(MSrcState8 &st, float slope, co
     }
     float bdf2 = 0.f;
     float4 bacc0 = make_float4(0.f, 0.f, 0.f, 0.f), bacc1 = bacc0;
+    const float inv_keep = DROP ? 1.0f / coef_keep : 1.0f;
 #pragma unroll
     for (int t = 0; t < U; ++t) {
         const float z = f1v[t] + f2v;
         const float alpha = exp_neg((SOFT ? leaky(z, slope) + bv[t] : leaky(z, slope)) - lsev[t]);
-        const float dalpha = group_sum<LPH8>(dot4(g0[t], wh0) + dot4(g1[t], wh1));
+        float dalpha = group_sum<LPH8>(dot4(g0[t], wh0) + dot4(g1[t], wh1));
+        float aa = alpha;
+        if (DROP) {
+            if (coef_keep < 1.f) {
+                const float mk = keep_mask(seed, cbase + (uint64_t)(uint32_t)i[t] * (uint64_t)(N * H), coef_keep) ? inv_keep : 0.f;
+                aa = alpha * mk;
+                dalpha *= mk;
+            }
+        }
         bdf2 += alpha * (dalpha - cv[t]) * (z > 0.f ? 1.f : slope);
-        bacc0 = f4_fma(alpha, g0[t], bacc0);
-        bacc1 = f4_fma(alpha, g1[t], bacc1);
+        bacc0 = f4_fma(aa, g0[t], bacc0);
+        bacc1 = f4_fma(aa, g1[t], bacc1);
     }
     st.acc0 = f4_add(st.acc0, bacc0);
     st.acc1 = f4_add(st.acc1, bacc1);
@@ -1235,8 +1313,14 @@ static inline size_t graph8_bwd_lds(int N, int H, int lc, int waves) {
     const size_t block_sum = (size_t)waves * 64 * sizeof(float4);
     return (size_t)(N + kGraphPadRows) * (64 + 3 * H) * sizeof(float) + (size_t)N * W * sizeof(uint32_t) + std::max(lists, block_sum);
 }
+// with prebuilt lists: g | stats | max(block sum area, list offsets + column order + `cap` list entries)
+static inline size_t graph8_bwd_lists_lds(int N, int H, int cap, int waves) {
+    const size_t lists = graph8_lists_head_lds(N) + (size_t)cap * sizeof(uint16_t);
+    const size_t block_sum = (size_t)waves * 64 * sizeof(float4);
+    return (size_t)(N + kGraphPadRows) * (64 + 3 * H) * sizeof(float) + std::max(lists, block_sum);
+}
 
-template <int LPH8, bool FUSED>
+template <int LPH8, bool FUSED, bool LISTS, bool DROP>
 __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(MaskedBwdArgs a, int lc) {
     constexpr int G = 16;
     constexpr int H = 8 / LPH8;
@@ -1251,9 +1335,14 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
     const int64_t b = blockIdx.x;
     float *gs = reinterpret_cast<float *>(graph_smem);                        // [NP][HD]
     float *ss = gs + NP * HD;                                                 // [NP][3H]
-    uint32_t *ps = reinterpret_cast<uint32_t *>(ss + NP * 3 * H);             // [N][W]
-    uint16_t *lists = reinterpret_cast<uint16_t *>(ps + N * W) + wave * kGraphWalkRows * lc;      // N * W even (N % 4 == 0): 8-byte aligned
-    int *cnt = reinterpret_cast<int *>(reinterpret_cast<uint16_t *>(ps + N * W) + nwaves * kGraphWalkRows * lc) + wave * kGraphWalkRows;
+    uint32_t *ps = reinterpret_cast<uint32_t *>(ss + NP * 3 * H);             // [N][W] (compaction mode)
+    unsigned char *area = reinterpret_cast<unsigned char *>(LISTS ? ps : ps + N * W);      // block-sum area, then the lists
+    uint16_t *lists = reinterpret_cast<uint16_t *>(area) + (LISTS ? 0 : wave * kGraphWalkRows * lc);      // N * W even (N % 4 == 0): 8-byte aligned
+    int *cnt = reinterpret_cast<int *>(reinterpret_cast<uint16_t *>(area) + nwaves * kGraphWalkRows * lc) + wave * kGraphWalkRows;
+    int *off_s = reinterpret_cast<int *>(area);
+    uint16_t *ord_s = reinterpret_cast<uint16_t *>(off_s + ((N + 2) & ~1));
+    if constexpr (LISTS) lists = ord_s + ((N + 3) & ~3);
+    const uint64_t seed = DROP ? seed_now(a) : 0;
     if (!FUSED) {
         const float4 *src = reinterpret_cast<const float4 *>(a.g + b * N * (int64_t)HD);
         for (int e = threadIdx.x; e < NP * (HD / 4); e += blockDim.x)
@@ -1329,7 +1418,7 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
         }
         if (a.dbias_ws) {
             // lanes with equal `sub` across the block, summed in a fixed order through the (not yet used) list area
-            float4 *red = reinterpret_cast<float4 *>(reinterpret_cast<uint16_t *>(ps + N * W));
+            float4 *red = reinterpret_cast<float4 *>(area);
             red[threadIdx.x] = gsum;
             __syncthreads();
             if (threadIdx.x < G) {
@@ -1342,22 +1431,27 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
     }
     // `graph_soft`: some row of this graph carries biases that must be added to its logits (its flag word is
     // set).  Hard masks, the usual case, have none: the list building below then skips the flag words altogether.
-    int soft_seen = 0;
-    {
+    bool graph_soft = false;
+    if constexpr (LISTS) {
+        stage_graph_lists(b, N, a.lptr, a.lcol, a.lord, a.lcap, off_s, ord_s, lists);
+        __syncthreads();
+    } else {
+        int soft_seen = 0;
         const uint32_t *src3 = a.present + b * N * (int64_t)W;
         for (int e = threadIdx.x; e < N * W; e += blockDim.x) {
             const uint32_t w = src3[e];
             ps[e] = w;
             soft_seen |= (e % W == W - 1) ? (int)w : 0;
         }
+        graph_soft = __syncthreads_or(soft_seen) != 0;
     }
-    const bool graph_soft = __syncthreads_or(soft_seen) != 0;
     const int c8 = lane >> 3, s8 = lane & 7;
     const int head8 = s8 / LPH8;
     const float *gl = gs + s8 * 8;
     const float *sl = ss + head8;
     for (int j0 = wave * kGraphWalkRows; j0 < N; j0 += nwaves * kGraphWalkRows) {
         bool anysoft = false;
+        if constexpr (!LISTS) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int q0 = j0 + 4 * half;
@@ -1410,28 +1504,53 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int jcol = min(j0 + c8, N - 1);
+        }
         const bool col_ok = j0 + c8 < N;
+        int jcol, total;
+        const uint16_t *lrow;
+        if constexpr (LISTS) {
+            jcol = ord_s[min(j0 + c8, N - 1)];
+            const int o0 = off_s[jcol];
+            total = col_ok ? off_s[jcol + 1] - o0 : 0;
+            lrow = lists + o0;
+        } else {
+            jcol = min(j0 + c8, N - 1);
+            total = cnt[c8];
+            lrow = lists + c8 * lc;
+        }
         const int64_t j = b * N + jcol;
-        const int total = cnt[c8];
-        const uint16_t *lrow = lists + c8 * lc;
         const float f2v = a.f2[j * H + head8];
-        const float4 wh0 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + s8 * 8);
-        const float4 wh1 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + s8 * 8 + 4);
+        float4 wh0 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + s8 * 8);
+        float4 wh1 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + s8 * 8 + 4);
+        if (DROP) {
+            if (a.feat_keep < 1.f) {
+                wh0 = drop_feat(wh0, seed, j, HD, s8 * 8, a.feat_keep);
+                wh1 = drop_feat(wh1, seed, j, HD, s8 * 8 + 4, a.feat_keep);
+            }
+        }
+        const uint64_t cbase = DROP ? ((uint64_t)(b * N) * (uint64_t)N + (uint64_t)jcol) * H + head8 : 0;
         MSrcState8 st;
         st.acc0 = st.acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
         st.df2 = 0.f;
         {
-            const float *bmcol = a.bias_mat + b * N * (int64_t)N + jcol;
-            if (anysoft) {
-                for (int k = 0; k < total; k += kGraphBatch) graph_bwd_batch8<LPH8, true>(st, a.slope, lrow + k, bmcol, N, gl, sl, f2v, wh0, wh1);
+            const float *bmcol = LISTS ? nullptr : a.bias_mat + b * N * (int64_t)N + jcol;
+            if (!LISTS && anysoft) {
+                for (int k = 0; k < total; k += kGraphBatch)
+                    graph_bwd_batch8<LPH8, !LISTS, DROP>(st, a.slope, lrow + k, bmcol, N, gl, sl, f2v, wh0, wh1, seed, cbase, a.coef_keep);
             } else {
-                for (int k = 0; k < total; k += kGraphBatch) graph_bwd_batch8<LPH8, false>(st, a.slope, lrow + k, bmcol, N, gl, sl, f2v, wh0, wh1);
+                for (int k = 0; k < total; k += kGraphBatch)
+                    graph_bwd_batch8<LPH8, false, DROP>(st, a.slope, lrow + k, bmcol, N, gl, sl, f2v, wh0, wh1, seed, cbase, a.coef_keep);
             }
         }
-        __builtin_amdgcn_wave_barrier();                 // every lane is done with the lists before the next columns overwrite them
+        if constexpr (!LISTS) __builtin_amdgcn_wave_barrier();   // every lane is done with the lists before the next columns overwrite them
         if (col_ok) {
             float4 r0 = st.acc0, r1 = st.acc1;
+            if (DROP) {
+                if (a.feat_keep < 1.f) {
+                    r0 = drop_feat(r0, seed, j, HD, s8 * 8, a.feat_keep);
+                    r1 = drop_feat(r1, seed, j, HD, s8 * 8 + 4, a.feat_keep);
+                }
+            }
             if (a.a1) {
                 const float d1 = (FUSED ? a.df1_out : a.df1)[j * H + head8];
                 r0 = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + s8 * 8), r0);
@@ -1464,6 +1583,89 @@ __global__ void graph_dbias_stage_kernel(const float *ws, int rows, int width, f
     if (ok && threadIdx.y == 0) out[(int64_t)blockIdx.y * width + c] = t;
 }
 
+// ------------------------------------------------------------------------------------------
+// Prebuilt lists for a mask that stays the same step after step (the reference feeds one bias_mat
+// every epoch, execute_cora.py:100-107): bits of the visited entries, list lengths, lists.
+// ------------------------------------------------------------------------------------------
+// One wave per mask row: the `present` words of that row (bit j of the row = entry j is within 1e6 of the row
+// maximum) and, in the flag word, whether the bias values matter to the row's softmax, so that lists alone cannot
+// stand for the mask: some visited entry differs from the row maximum, or several entries share a maximum so
+// large that fp32 rounds the logits added to it (a row masked everywhere attends uniformly, utils/layers.py:17).
+__global__ __launch_bounds__(256) void mask_bits_kernel(const float *bias_mat, int N, int W, float shared_limit, uint32_t *bits) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b = blockIdx.x;
+    const int i = blockIdx.y * 4 + wave;
+    if (i >= N) return;
+    const float *bm = bias_mat + (b * N + i) * (int64_t)N;
+    float mx = -INFINITY;
+    for (int j = lane; j < N; j += 64) mx = fmaxf(mx, bm[j]);
+    mx = wave_max(mx);
+    const float cut = mx - kMaskCutoffFwd;
+    uint32_t *prow = bits + (b * N + i) * (int64_t)W;
+    uint64_t differs = 0;
+    int visited = 0;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int j = j0 + lane;
+        const float v = j < N ? bm[j] : -INFINITY;
+        const bool present = v > cut;
+        const uint64_t bal = __ballot(present);
+        visited += __popcll(bal);
+        differs |= __ballot(present && v != mx);
+        if (lane < 2 && (j0 >> 5) + lane < W - 1) prow[(j0 >> 5) + lane] = (uint32_t)(bal >> (32 * lane));
+    }
+    if (lane == 0) prow[W - 1] = (differs != 0 || (fabsf(mx) > shared_limit && visited > 1) || !(mx == mx)) ? 1u : 0u;
+}
+
+constexpr int kListsThreads = 256;
+
+// block per graph: padded list lengths of its rows (visited columns) and of its columns (visiting rows)
+__global__ __launch_bounds__(kListsThreads) void lists_count_kernel(const uint32_t *bits, int N, int W, int32_t *row_cnt, int32_t *col_cnt) {
+    extern __shared__ uint32_t lists_bits[];
+    const int64_t b = blockIdx.x;
+    for (int e = threadIdx.x; e < N * W; e += blockDim.x) lists_bits[e] = bits[b * N * (int64_t)W + e];
+    __syncthreads();
+    for (int r = threadIdx.x; r < N; r += blockDim.x) {
+        int n = 0;
+        for (int w = 0; w < W - 1; ++w) n += __popc(lists_bits[r * W + w]);
+        row_cnt[b * N + r] = (n + kGraphBatch - 1) / kGraphBatch * kGraphBatch;
+    }
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+        int n = 0;
+        for (int i = 0; i < N; ++i) n += (lists_bits[i * W + (c >> 5)] >> (c & 31)) & 1u;
+        col_cnt[b * N + c] = (n + kGraphBatch - 1) / kGraphBatch * kGraphBatch;
+    }
+}
+
+// block per graph: the lists themselves, each in the order in which the compacting kernels build it (a lane group of
+// 16 appends lane by lane: lane `sub` holds columns 64k + 4 sub + c of a row, rows 16 r + sub of a column), so that
+// the kernels that walk prebuilt lists add the same terms in the same order as the kernels that read the mask.
+__global__ __launch_bounds__(kListsThreads) void lists_fill_kernel(const uint32_t *bits, int N, int W, const int32_t *lptr, const int32_t *cptr,
+                                                                   uint16_t *lcol, uint16_t *crow) {
+    extern __shared__ uint32_t lists_bits[];
+    const int64_t b = blockIdx.x;
+    for (int e = threadIdx.x; e < N * W; e += blockDim.x) lists_bits[e] = bits[b * N * (int64_t)W + e];
+    __syncthreads();
+    for (int r = threadIdx.x; r < N; r += blockDim.x) {
+        int at = lptr[b * N + r];
+        const int end = lptr[b * N + r + 1];
+        for (int sub = 0; sub < 16; ++sub)
+            for (int k = 0; 64 * k + 4 * sub < N; ++k)
+                for (int c = 0; c < 4; ++c) {
+                    const int col = 64 * k + 4 * sub + c;
+                    if (col < N && ((lists_bits[r * W + (col >> 5)] >> (col & 31)) & 1u) && at < end) lcol[at++] = (uint16_t)col;
+                }
+        while (at < end) lcol[at++] = (uint16_t)N;
+    }
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+        int at = cptr[b * N + c];
+        const int end = cptr[b * N + c + 1];
+        for (int sub = 0; sub < 16; ++sub)
+            for (int i = sub; i < N; i += 16)
+                if (((lists_bits[i * W + (c >> 5)] >> (c & 31)) & 1u) && at < end) crow[at++] = (uint16_t)i;
+        while (at < end) crow[at++] = (uint16_t)N;
+    }
+}
+
 // (G, LPH) pairs built: rows of 32..256 floats (narrower rows leave most of a wave idle in the
 // compaction; those shapes stay with the matrix-core kernels)
 #define GATMI_MASKED_SHAPES(X) X(8, 1) X(8, 2) X(8, 4) X(8, 8) X(16, 1) X(16, 2) X(16, 4) X(16, 8) X(16, 16) \
@@ -1472,6 +1674,56 @@ __global__ void graph_dbias_stage_kernel(const float *ws, int rows, int width, f
 }  // namespace gatmi
 
 using namespace gatmi;
+
+// shapes of the graph-resident kernels with the eight-lane walk: rows of 64 floats in heads of >= 8, graphs of
+// 4 .. 320 nodes (a multiple of 4), one block per graph and at least one block per CU
+static bool graph8_shape(int64_t B, int32_t N, int G, int LPH) {
+    return G == 16 && LPH >= 2 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && B <= 0x7fffffff;
+}
+
+template <bool LISTS>
+static int launch_graph_fwd8(const MaskedFwdArgs &a, int LPH, bool save, bool drop, size_t lds, int lc, hipStream_t st, const char *name) {
+    const int waves = graph8_waves(a.N);
+    hipError_t e = hipSuccess;
+#define GATMI_L(ll, sv, dr)                                                                                          \
+    {                                                                                                                \
+        if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_fwd8_kernel<ll, sv, LISTS, dr>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_fwd8_kernel<ll, sv, LISTS, dr>), dim3((unsigned)a.B), dim3(64 * waves), lds, st, a, lc); \
+    }
+#define X(ll)                                                                                                        \
+    if (LPH == 2 * ll) {                                                                                            \
+        if (drop) GATMI_L(ll, true, true) else if (save) GATMI_L(ll, true, false) else GATMI_L(ll, false, false)     \
+        if (e != hipSuccess) return fail(GATMI_EHIP, "%s: %s", name, hipGetErrorString(e));                         \
+        GATMI_LAUNCH_CHECK(name);                                                                                   \
+        return GATMI_OK;                                                                                            \
+    }
+    X(1) X(2) X(4) X(8)
+#undef X
+#undef GATMI_L
+    return fail(GATMI_EUNSUPPORTED, "%s: no kernel for %d lanes per head", name, LPH);
+}
+
+template <bool LISTS>
+static int launch_graph_bwd8_fused(const MaskedBwdArgs &a, int LPH, bool drop, size_t lds, int lc, hipStream_t st, const char *name) {
+    const int waves = graph8_waves(a.N);
+    hipError_t e = hipSuccess;
+#define GATMI_L(ll, dr)                                                                                              \
+    {                                                                                                                \
+        if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_bwd8_kernel<ll, true, LISTS, dr>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_bwd8_kernel<ll, true, LISTS, dr>), dim3((unsigned)a.B), dim3(64 * waves), lds, st, a, lc); \
+    }
+#define X(ll)                                                                                                        \
+    if (LPH == 2 * ll) {                                                                                            \
+        if (drop) GATMI_L(ll, true) else GATMI_L(ll, false)                                                          \
+        if (e != hipSuccess) return fail(GATMI_EHIP, "%s: %s", name, hipGetErrorString(e));                         \
+        GATMI_LAUNCH_CHECK(name);                                                                                   \
+        return GATMI_OK;                                                                                            \
+    }
+    X(1) X(2) X(4) X(8)
+#undef X
+#undef GATMI_L
+    return fail(GATMI_EUNSUPPORTED, "%s: no kernel for %d lanes per head", name, LPH);
+}
 
 static int masked_check(int64_t B, int32_t N, int32_t H, int32_t dp, int *G, int *LPH, const char *name) {
     int rc = check_shape(H, dp, G, LPH);
@@ -1512,26 +1764,9 @@ extern "C" int gatmi_dense_attn_fwd_masked(int64_t B, int32_t N, int32_t H, int3
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // many small graphs: one block per graph with the graph's rows resident in LDS
     const int lc = graph_list_capacity(N);
-    if (!drop && G == 16 && LPH >= 2 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch &&
-        graph8_fwd_lds(N, H, lc, graph8_waves(N)) <= graph_lds_limit()) {
-        const int waves = graph8_waves(N);
-        const size_t lds = graph8_fwd_lds(N, H, lc, waves);
-        hipError_t e = hipSuccess;
-#define X(ll)                                                                                                      \
-        if (LPH == 2 * ll) {                                                                                      \
-            if (save) {                                                                                           \
-                if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_fwd8_kernel<ll, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_fwd8_kernel<ll, true>), dim3((unsigned)B), dim3(64 * waves), lds, st, a, lc); \
-            } else {                                                                                              \
-                if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_fwd8_kernel<ll, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_fwd8_kernel<ll, false>), dim3((unsigned)B), dim3(64 * waves), lds, st, a, lc); \
-            }                                                                                                     \
-            if (e != hipSuccess) return fail(GATMI_EHIP, "dense_attn_fwd_masked: %s", hipGetErrorString(e));       \
-            GATMI_LAUNCH_CHECK("dense_attn_fwd_masked (graph-resident, eight-lane walk)");                        \
-            return GATMI_OK;                                                                                      \
-        }
-        X(1) X(2) X(4) X(8)
-#undef X
+    if (graph8_shape(B, N, G, LPH) && graph8_fwd_lds(N, H, lc, graph8_waves(N)) <= graph_lds_limit()) {
+        a.lptr = nullptr; a.lcol = a.lord = nullptr; a.lcap = 0;
+        return launch_graph_fwd8<false>(a, LPH, save, drop, graph8_fwd_lds(N, H, lc, graph8_waves(N)), lc, st, "dense_attn_fwd_masked (graph-resident, eight-lane walk)");
     }
     if (!drop && G == 16 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && graph_fwd_lds(N, G, H, lc) <= graph_lds_limit()) {
         const size_t lds = graph_fwd_lds(N, G, H, lc);
@@ -1595,8 +1830,8 @@ extern "C" int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int3
         hipError_t e = hipSuccess;
 #define X(ll)                                                                                                      \
         if (LPH == 2 * ll) {                                                                                      \
-            if (glds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_bwd8_kernel<ll, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds); \
-            if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_bwd8_kernel<ll, false>), dim3((unsigned)B), dim3(64 * waves), glds, st, a, lcg); \
+            if (glds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_bwd8_kernel<ll, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds); \
+            if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_bwd8_kernel<ll, false, false, false>), dim3((unsigned)B), dim3(64 * waves), glds, st, a, lcg); \
             if (e != hipSuccess) return fail(GATMI_EHIP, "dense_attn_bwd_masked: %s", hipGetErrorString(e));       \
             GATMI_LAUNCH_CHECK("dense_attn_bwd_masked (graph-resident, eight-lane walk)");                        \
             return GATMI_OK;                                                                                      \
@@ -1636,15 +1871,14 @@ extern "C" int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int3
 // ------------------------------------------------------------------------------------------
 // backward for batches of many small graphs with the per-destination step fused in
 // ------------------------------------------------------------------------------------------
-static bool graph_fused_shape(int64_t B, int32_t N, int G, int LPH, int H, float coef_keep, float feat_keep) {
-    const bool drop = coef_keep < 1.f || feat_keep < 1.f;
-    return !drop && G == 16 && LPH >= 2 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && B <= 0x7fffffff &&
-           graph8_bwd_lds(N, H, graph_list_capacity(N), graph8_waves(N)) <= graph_lds_limit();
+static bool graph_fused_shape(int64_t B, int32_t N, int G, int LPH, int H) {
+    return graph8_shape(B, N, G, LPH) && graph8_bwd_lds(N, H, graph_list_capacity(N), graph8_waves(N)) <= graph_lds_limit();
 }
 
 extern "C" int gatmi_dense_attn_bwd_fused_ok(int64_t B, int32_t N, int32_t H, int32_t dp, float coef_keep, float feat_keep) {
     if (H <= 0 || dp < 4 || !is_pow2(dp) || !is_pow2(H) || (int64_t)H * dp > 256) return 0;
-    return graph_fused_shape(B, N, H * dp / 4, dp / 4, H, coef_keep, feat_keep) ? 1 : 0;
+    if (!(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f)) return 0;
+    return graph_fused_shape(B, N, H * dp / 4, dp / 4, H) ? 1 : 0;
 }
 
 extern "C" size_t gatmi_dense_attn_bwd_fused_ws_floats(int64_t B, int32_t H, int32_t dp) {
@@ -1652,45 +1886,143 @@ extern "C" size_t gatmi_dense_attn_bwd_fused_ws_floats(int64_t B, int32_t H, int
     return B <= 0 ? 0 : (size_t)(B + (B + kDbiasStageRows - 1) / kDbiasStageRows) * (size_t)H * dp;
 }
 
+extern "C" int64_t gatmi_dense_lists_capacity(int32_t N, int32_t H, int32_t dp, int32_t backward) {
+    if (H <= 0 || dp < 8 || !is_pow2(dp) || !is_pow2(H) || H * dp != 64 || N < 4 || (N & 3) || N > kGraphMaxN) return 0;
+    const size_t fixed = backward ? graph8_bwd_lists_lds(N, H, 0, 0) : graph8_fwd_lists_lds(N, H, 0);
+    const size_t limit = graph_lds_limit();
+    if (fixed + 64 >= limit) return 0;
+    return (int64_t)((limit - fixed) / sizeof(uint16_t)) & ~(int64_t)3;
+}
+
+extern "C" int gatmi_dense_mask_bits(int64_t B, int32_t N, const float *bias_mat, float shared_limit, uint32_t *bits, void *stream) {
+    GATMI_REQUIRE(B >= 0 && N >= 0, GATMI_EINVAL, "dense_mask_bits: negative size");
+    if (B == 0 || N == 0) return GATMI_OK;
+    GATMI_REQUIRE(bias_mat && bits, GATMI_EINVAL, "dense_mask_bits: null pointer");
+    GATMI_REQUIRE(B <= 0x7fffffff && (N + 3) / 4 <= 65535, GATMI_ERANGE, "dense_mask_bits: too large for one launch");
+    const int W = (N + 31) / 32 + 1;
+    hipLaunchKernelGGL(mask_bits_kernel, dim3((unsigned)B, (unsigned)((N + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), bias_mat, N, W, shared_limit, bits);
+    GATMI_LAUNCH_CHECK("dense_mask_bits");
+    return GATMI_OK;
+}
+
+static int lists_check(int64_t B, int32_t N, const char *name) {
+    GATMI_REQUIRE(B >= 0 && N >= 0, GATMI_EINVAL, "%s: negative size", name);
+    GATMI_REQUIRE(N >= 4 && (N & 3) == 0 && N <= kGraphMaxN, GATMI_EUNSUPPORTED,
+                  "%s: prebuilt lists are for the graph-resident kernels (graphs of 4 .. %d nodes, a multiple of 4), N = %d", name, kGraphMaxN, N);
+    GATMI_REQUIRE(B <= 0x7fffffff && B * (int64_t)N < 0x7fffffff, GATMI_ERANGE, "%s: too large for one launch", name);
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_dense_lists_count(int64_t B, int32_t N, const uint32_t *bits, int32_t *row_cnt, int32_t *col_cnt, void *stream) {
+    if (B == 0) return GATMI_OK;
+    int rc = lists_check(B, N, "dense_lists_count");
+    if (rc) return rc;
+    GATMI_REQUIRE(bits && row_cnt && col_cnt, GATMI_EINVAL, "dense_lists_count: null pointer");
+    const int W = (N + 31) / 32 + 1;
+    hipLaunchKernelGGL(lists_count_kernel, dim3((unsigned)B), dim3(kListsThreads), (size_t)N * W * sizeof(uint32_t), reinterpret_cast<hipStream_t>(stream),
+                       bits, N, W, row_cnt, col_cnt);
+    GATMI_LAUNCH_CHECK("dense_lists_count");
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_dense_lists_fill(int64_t B, int32_t N, const uint32_t *bits, const int32_t *lptr, const int32_t *cptr,
+                                      uint16_t *lcol, uint16_t *crow, void *stream) {
+    if (B == 0) return GATMI_OK;
+    int rc = lists_check(B, N, "dense_lists_fill");
+    if (rc) return rc;
+    GATMI_REQUIRE(bits && lptr && cptr && lcol && crow, GATMI_EINVAL, "dense_lists_fill: null pointer");
+    const int W = (N + 31) / 32 + 1;
+    hipLaunchKernelGGL(lists_fill_kernel, dim3((unsigned)B), dim3(kListsThreads), (size_t)N * W * sizeof(uint32_t), reinterpret_cast<hipStream_t>(stream),
+                       bits, N, W, lptr, cptr, lcol, crow);
+    GATMI_LAUNCH_CHECK("dense_lists_fill");
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_dense_attn_fwd_lists(int64_t B, int32_t N, int32_t H, int32_t dp,
+                                          const float *Wh, const float *f1, const float *f2,
+                                          const int32_t *lptr, const uint16_t *lcol, const uint16_t *lord, int64_t max_entries,
+                                          const float *bias, const float *resid, int32_t activation, float slope,
+                                          float coef_keep, float feat_keep, uint64_t seed,
+                                          float *out, float *agg, float *pos, float *lse, float *q, void *stream) {
+    int G, LPH;
+    int rc = masked_check(B, N, H, dp, &G, &LPH, "dense_attn_fwd_lists");
+    if (rc) return rc;
+    if (B == 0 || N == 0) return GATMI_OK;
+    GATMI_REQUIRE(Wh && f1 && f2 && lptr && lcol && lord && out, GATMI_EINVAL, "dense_attn_fwd_lists: null pointer");
+    GATMI_REQUIRE(graph8_shape(B, N, G, LPH), GATMI_EUNSUPPORTED,
+                  "dense_attn_fwd_lists: B=%lld N=%d H=%d dp=%d is not a shape of the graph-resident kernels (rows of 64 floats in heads of >= 8, "
+                  "graphs of 4 .. %d nodes, at least %lld graphs)", (long long)B, N, H, dp, kGraphMaxN, (long long)kGraphMinBatch);
+    const int64_t cap_max = gatmi_dense_lists_capacity(N, H, dp, 0);
+    GATMI_REQUIRE(max_entries >= 0 && max_entries <= cap_max, GATMI_ERANGE,
+                  "dense_attn_fwd_lists: a graph with %lld list entries does not fit beside its rows in LDS (at most %lld here); use gatmi_dense_attn_fwd_masked",
+                  (long long)max_entries, (long long)cap_max);
+    GATMI_REQUIRE(act_known(activation), GATMI_EUNSUPPORTED, "dense_attn_fwd_lists: activation %d", activation);
+    const bool save = agg || pos || lse || q;
+    GATMI_REQUIRE(!save || (agg && pos && lse && q), GATMI_EINVAL, "dense_attn_fwd_lists: agg, pos, lse, q must be given together");
+    GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "dense_attn_fwd_lists: keep probabilities must be in (0,1]");
+    const bool drop = coef_keep < 1.f || feat_keep < 1.f;
+    GATMI_REQUIRE(!drop || save, GATMI_EINVAL, "dense_attn_fwd_lists: dropout is a training-time option and needs agg, pos, lse, q");
+    GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(out); GATMI_REQUIRE_ALIGNED(bias); GATMI_REQUIRE_ALIGNED(resid);
+    GATMI_REQUIRE_ALIGNED(agg); GATMI_REQUIRE_ALIGNED(pos);
+    GATMI_REQUIRE((reinterpret_cast<uintptr_t>(lcol) & 7u) == 0, GATMI_EALIGN, "dense_attn_fwd_lists: lcol is not 8-byte aligned");
+    MaskedFwdArgs a;
+    a.B = B; a.N = N; a.Wh = Wh; a.f1 = f1; a.f2 = f2; a.bias_mat = nullptr; a.bias = bias; a.resid = resid;
+    a.out = out; a.agg = agg; a.pos = pos; a.lse = lse; a.q = q; a.activation = activation; a.slope = slope;
+    a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.seed_step = drop ? dropout_step_source() : nullptr; a.present = nullptr;
+    const int cap = (int)((max_entries + 3) & ~(int64_t)3);
+    a.lptr = lptr; a.lcol = lcol; a.lord = lord; a.lcap = cap;
+    return launch_graph_fwd8<true>(a, LPH, save, drop, graph8_fwd_lists_lds(N, H, cap), 0, reinterpret_cast<hipStream_t>(stream), "dense_attn_fwd_lists");
+}
+
 extern "C" int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32_t dp,
                                           const float *dout, const float *out, const float *agg, const float *pos,
                                           const float *q, const float *f1, const float *lse, const float *bias, int32_t activation,
                                           const float *Wh, const float *f2, const float *bias_mat, const uint32_t *present,
+                                          const int32_t *cptr, const uint16_t *crow, const uint16_t *cord, int64_t max_entries,
                                           const float *a1, const float *a2, float slope,
+                                          float coef_keep, float feat_keep, uint64_t seed,
                                           float *g, float *df1, float *dbias, float *ws,
                                           float *dWh, float *df2, void *stream) {
     int G, LPH;
     int rc = masked_check(B, N, H, dp, &G, &LPH, "dense_attn_bwd_fused");
     if (rc) return rc;
     if (B == 0 || N == 0) return GATMI_OK;
-    GATMI_REQUIRE(graph_fused_shape(B, N, G, LPH, H, 1.f, 1.f), GATMI_EUNSUPPORTED,
+    GATMI_REQUIRE(graph_fused_shape(B, N, G, LPH, H), GATMI_EUNSUPPORTED,
                   "dense_attn_bwd_fused: B=%lld N=%d H=%d dp=%d is not a shape of the graph-resident kernels (ask gatmi_dense_attn_bwd_fused_ok)",
                   (long long)B, N, H, dp);
-    GATMI_REQUIRE(dout && agg && pos && q && f1 && lse && Wh && f2 && bias_mat && present && df1 && dWh && df2, GATMI_EINVAL, "dense_attn_bwd_fused: null pointer");
+    const bool lists = cptr != nullptr;
+    GATMI_REQUIRE(dout && agg && pos && q && f1 && lse && Wh && f2 && df1 && dWh && df2, GATMI_EINVAL, "dense_attn_bwd_fused: null pointer");
+    GATMI_REQUIRE(lists ? (crow && cord) : (bias_mat && present), GATMI_EINVAL,
+                  "dense_attn_bwd_fused: give either the mask with the forward pass's `present` bits, or prebuilt lists (cptr, crow, cord)");
     GATMI_REQUIRE((a1 == nullptr) == (a2 == nullptr), GATMI_EINVAL, "dense_attn_bwd_fused: a1 and a2 go together");
     GATMI_REQUIRE(!dbias || ws, GATMI_EINVAL, "dense_attn_bwd_fused: dbias needs ws (gatmi_dense_attn_bwd_fused_ws_floats)");
     GATMI_REQUIRE(act_known(activation), GATMI_EUNSUPPORTED, "dense_attn_bwd_fused: activation %d", activation);
+    GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "dense_attn_bwd_fused: keep probabilities must be in (0,1]");
+    const bool drop = coef_keep < 1.f || feat_keep < 1.f;
     GATMI_REQUIRE_ALIGNED(dout); GATMI_REQUIRE_ALIGNED(out); GATMI_REQUIRE_ALIGNED(agg); GATMI_REQUIRE_ALIGNED(pos); GATMI_REQUIRE_ALIGNED(bias);
     GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(g); GATMI_REQUIRE_ALIGNED(dWh); GATMI_REQUIRE_ALIGNED(a1); GATMI_REQUIRE_ALIGNED(a2); GATMI_REQUIRE_ALIGNED(ws);
     MaskedBwdArgs a{};
     a.B = B; a.N = N; a.Wh = Wh; a.f2 = f2; a.bias_mat = bias_mat; a.a1 = a1; a.a2 = a2; a.present = present;
-    a.dWh = dWh; a.df2 = df2; a.slope = slope; a.coef_keep = 1.f; a.feat_keep = 1.f; a.seed = 0;
+    a.dWh = dWh; a.df2 = df2; a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
+    a.seed_step = drop ? dropout_step_source() : nullptr;
     a.dout = dout; a.out = out; a.agg = agg; a.pos = pos; a.q = q; a.f1 = f1; a.lse = lse; a.bias = out ? nullptr : bias;
     a.g_out = g; a.df1_out = df1; a.dbias_ws = dbias ? ws : nullptr; a.activation = activation;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int lc = graph_list_capacity(N);
     const int waves = graph8_waves(N);
-    const size_t lds = graph8_bwd_lds(N, H, lc, waves);
-    hipError_t e = hipSuccess;
-#define X(ll)                                                                                                      \
-    if (LPH == 2 * ll) {                                                                                          \
-        if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_bwd8_kernel<ll, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_bwd8_kernel<ll, true>), dim3((unsigned)B), dim3(64 * waves), lds, st, a, lc); \
-        if (e != hipSuccess) return fail(GATMI_EHIP, "dense_attn_bwd_fused: %s", hipGetErrorString(e));               \
-        GATMI_LAUNCH_CHECK("dense_attn_bwd_fused");                                                                   \
+    if (lists) {
+        const int64_t cap_max = gatmi_dense_lists_capacity(N, H, dp, 1);
+        GATMI_REQUIRE(max_entries >= 0 && max_entries <= cap_max, GATMI_ERANGE,
+                      "dense_attn_bwd_fused: a graph with %lld list entries does not fit beside its rows in LDS (at most %lld here); pass the mask and `present` instead",
+                      (long long)max_entries, (long long)cap_max);
+        GATMI_REQUIRE((reinterpret_cast<uintptr_t>(crow) & 7u) == 0, GATMI_EALIGN, "dense_attn_bwd_fused: crow is not 8-byte aligned");
+        const int cap = (int)((max_entries + 3) & ~(int64_t)3);
+        a.lptr = cptr; a.lcol = crow; a.lord = cord; a.lcap = cap;
+        rc = launch_graph_bwd8_fused<true>(a, LPH, drop, graph8_bwd_lists_lds(N, H, cap, waves), 0, st, "dense_attn_bwd_fused (prebuilt lists)");
+    } else {
+        const int lc = graph_list_capacity(N);
+        rc = launch_graph_bwd8_fused<false>(a, LPH, drop, graph8_bwd_lds(N, H, lc, waves), lc, st, "dense_attn_bwd_fused");
     }
-    X(1) X(2) X(4) X(8)
-#undef X
+    if (rc) return rc;
     if (dbias) {
         const int hd = H * dp;
         const float *rows = ws;

@@ -197,3 +197,58 @@ class CSRGraph:
     def __repr__(self):
         return "CSRGraph(n_dst=%d, n_src=%d, nnz=%d, chunk=%d, split rows csr/csc=%d/%d)" % (
             self.n_dst, self.n_src, self.nnz, self.chunk, len(self.split_csr), len(self.split_csc))
+
+
+class MaskLists:
+    """Prebuilt lists of a batch of dense additive masks [B,N,N] (adj_to_bias, utils/process.py:14-25) for the
+    graph-resident kernels: per graph, the columns every row visits and the rows that visit every column, in the
+    order in which the mask-reading kernels compact them, plus the graph's rows / columns ordered by list length.
+    Built once (a few launches and two prefix sums) for a mask that is fed unchanged step after step — the reference
+    feeds one bias_mat every epoch, execute_cora.py:100-107 — and passed where bias_mat went: the layer then neither
+    reads the N x N floats nor compacts anything, and its results are bit-identical to the mask-reading kernels'.
+    Hard masks only (every visited entry of a row carries the row's maximum, utils/layers.py:17 adds a constant
+    that cancels in the softmax): ValueError otherwise, as for CSRGraph.from_bias_mat."""
+
+    def __init__(self, bias_mat):
+        if bias_mat.dim() != 3 or bias_mat.shape[1] != bias_mat.shape[2] or not bias_mat.is_cuda or bias_mat.dtype != torch.float32:
+            raise ValueError("MaskLists: a [B,N,N] fp32 device tensor is expected")
+        bias_mat = bias_mat.contiguous()
+        B, N, _ = bias_mat.shape
+        dev = bias_mat.device
+        if B * N >= 2 ** 31 - 1 or N % 4 or not (4 <= N <= 320):
+            raise ValueError("MaskLists: graphs of 4..320 nodes (a multiple of 4) are covered, got N = %d" % N)
+        st = _lib.current_stream()
+        W = _lib.lib.gatmi_dense_mask_words(N)
+        bits = torch.empty((B * N, W), dtype=torch.int32, device=dev)
+        _lib.call("gatmi_dense_mask_bits", B, N, _lib.ptr(bias_mat), SHARED_BIAS_LIMIT, _lib.ptr(bits), st)
+        if bool(bits[:, W - 1].any()):
+            raise ValueError("MaskLists: some row's visited entries carry biases that matter to its softmax (they differ "
+                             "inside the row, or a large bias is shared by several entries); keep the mask dense")
+        row_cnt = torch.empty(B * N, dtype=torch.int32, device=dev)
+        col_cnt = torch.empty(B * N, dtype=torch.int32, device=dev)
+        _lib.call("gatmi_dense_lists_count", B, N, _lib.ptr(bits), _lib.ptr(row_cnt), _lib.ptr(col_cnt), st)
+
+        def prefix(cnt):
+            p = torch.zeros(B * N + 1, dtype=torch.int64, device=dev)
+            p[1:] = torch.cumsum(cnt, 0, dtype=torch.int64)
+            if int(p[-1]) >= 2 ** 31 - 1:
+                raise ValueError("MaskLists: more than 2^31 list entries")
+            per_graph = p[N::N] - p[:-1:N]
+            order = torch.argsort(cnt.view(B, N), dim=1, descending=True, stable=True).to(torch.int16)
+            return p.to(torch.int32), int(per_graph.max()), order.reshape(-1).contiguous()
+        self.lptr, self.max_fwd, self.lord = prefix(row_cnt)
+        self.cptr, self.max_bwd, self.cord = prefix(col_cnt)
+        self.lcol = torch.empty(max(int(self.lptr[-1]), 4), dtype=torch.int16, device=dev)
+        self.crow = torch.empty(max(int(self.cptr[-1]), 4), dtype=torch.int16, device=dev)
+        _lib.call("gatmi_dense_lists_fill", B, N, _lib.ptr(bits), _lib.ptr(self.lptr), _lib.ptr(self.cptr), _lib.ptr(self.lcol),
+                  _lib.ptr(self.crow), st)
+        self.B, self.N, self.device = B, N, dev
+        self.entries = int(row_cnt.sum())
+
+    def fits(self, H, dp):
+        """Whether the graph-resident kernels can hold every graph's lists beside its rows for heads of this shape."""
+        cap = _lib.lib.gatmi_dense_lists_capacity
+        return (self.B >= 256 and 0 < self.max_fwd <= cap(self.N, H, dp, 0) and 0 < self.max_bwd <= cap(self.N, H, dp, 1))
+
+    def __repr__(self):
+        return "MaskLists(B=%d, N=%d, list entries=%d, largest graph fwd/bwd=%d/%d)" % (self.B, self.N, self.entries, self.max_fwd, self.max_bwd)

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import ops
 from .features import SparseFeatures
-from .graph import CSRGraph
+from .graph import CSRGraph, MaskLists
 
 elu = "elu"
 identity = "identity"
@@ -59,7 +59,10 @@ class _MaskGraphs:
         if e is not None and e[0] is ref:
             del self._entries[key]
 
-    def lookup(self, t):
+    def lookup(self, t, heads=None):
+        """heads = (H, padded width) of the asking layer: when its rows are the 64 floats of the graph-resident
+        kernels and the batch is one of many small graphs, the memo holds prebuilt lists (MaskLists: built in a few
+        launches, results bit-identical to the mask-reading kernels) instead of a block-diagonal CSR graph."""
         if not self.enabled or not torch.is_tensor(t) or t.dim() != 3 or not t.is_cuda:
             return None
         e = self._entries.get(id(t))
@@ -76,10 +79,23 @@ class _MaskGraphs:
             e[2] = False
             if d is not None and d <= ops.MASK_LIST_DENSITY:
                 try:
-                    e[2] = CSRGraph.from_bias_mat(t)
+                    B, N = t.shape[:2]
+                    if B >= 256 and N % 4 == 0 and 4 <= N <= 320 and t.dtype == torch.float32:
+                        e[2] = MaskLists(t)
+                    else:
+                        e[2] = CSRGraph.from_bias_mat(t)
                 except ValueError:   # biases differ inside a row: the dense kernels add them
                     pass
-        return e[2] or None
+        g = e[2] or None
+        if isinstance(g, MaskLists) and not (heads and heads[0] * heads[1] == 64 and heads[1] >= 8 and g.fits(*heads)):
+            # this layer's rows are not those of the graph-resident kernels: it needs the CSR form of the same mask
+            if len(e) < 4:
+                try:
+                    e.append(CSRGraph.from_bias_mat(t) if not torch.cuda.is_current_stream_capturing() else None)
+                except ValueError:
+                    e.append(None)
+            return e[3]
+        return g
 
 
 mask_graphs = _MaskGraphs()
@@ -148,8 +164,11 @@ class GATHeads(nn.Module):
             if seed is None and training and (in_drop > 0.0 or coef_drop > 0.0):
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             return self._run(seq, graph_or_bias, slice(0, H), act, reduce, in_drop, coef_drop, training, seed)[None]
-        g = mask_graphs.lookup(graph_or_bias)                                # a dense mask met before, unchanged
-        if g is not None and seq.dim() == 3:
+        groups = _head_groups(H, D)
+        g = mask_graphs.lookup(graph_or_bias, (groups[0][1], ops.padded_width(D)) if len(groups) == 1 else None)   # a dense mask met before, unchanged
+        if isinstance(g, MaskLists) and seq.dim() == 3:
+            graph_or_bias = g                                                # same surface, the mask's lists instead of its floats
+        elif g is not None and seq.dim() == 3:
             return self.forward(seq, g, act, reduce, in_drop, coef_drop, training, seed)
         if training and in_drop > 0.0:
             seq = torch.nn.functional.dropout(seq, in_drop, True)            # layers.py:8-9

@@ -10,6 +10,7 @@ import torch
 from . import _lib
 from ._lib import ptr
 from .features import SparseFeatures
+from .graph import MaskLists
 
 LEAKY_SLOPE = 0.2  # tf.nn.leaky_relu default, utils/layers.py:17
 
@@ -319,15 +320,25 @@ class DenseGATLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, a1, a2, b1, b2, bias, W_res, b_res, bias_mat, cfg):
-        _require_cuda(x, W, bias_mat)
+        _require_cuda(x, W, None if isinstance(bias_mat, MaskLists) else bias_mat)
         if cfg.reduce != "concat":
             raise ValueError("dense layer: heads are concatenated by the kernel; average outside")
         x = _f32(x).contiguous()
         B, N, F = x.shape
-        bias_mat = _f32(bias_mat).contiguous()
-        if tuple(bias_mat.shape) != (B, N, N):
-            raise ValueError("bias_mat must be [B,N,N] = [%d,%d,%d], got %s" % (B, N, N, tuple(bias_mat.shape)))
-        cfg = _widen_for_lists(cfg, bias_mat)
+        mlists = bias_mat if isinstance(bias_mat, MaskLists) else None
+        if mlists is not None:
+            # prebuilt lists of a mask that does not change: no mask read, no compaction (same results bit for bit)
+            if (mlists.B, mlists.N) != (B, N):
+                raise ValueError("the lists were built for [%d,%d,%d] masks, the input is [%d,%d,.]" % (mlists.B, mlists.N, mlists.N, B, N))
+            if cfg.H * cfg.dp != 64 or cfg.dp < 8 or not mlists.fits(cfg.H, cfg.dp):
+                raise ValueError("MaskLists go with the graph-resident kernels: rows of 64 floats in heads of >= 8, at least 256 "
+                                 "graphs whose lists fit beside their rows in LDS (heads=%d width=%d, %r)" % (cfg.H, cfg.dp, mlists))
+            bias_mat = None
+        else:
+            bias_mat = _f32(bias_mat).contiguous()
+            if tuple(bias_mat.shape) != (B, N, N):
+                raise ValueError("bias_mat must be [B,N,N] = [%d,%d,%d], got %s" % (B, N, N, tuple(bias_mat.shape)))
+            cfg = _widen_for_lists(cfg, bias_mat)
         H, D, dp = cfg.H, cfg.D, cfg.dp
         hd = H * dp
         st = _lib.current_stream()
@@ -341,9 +352,13 @@ class DenseGATLayerFn(torch.autograd.Function):
         if need_grad or dropping:
             agg, pos = _new((B * N, hd), x), _new((B * N, hd), x)
             lse, q = _new((B * N, H), x), _new((B * N, H), x)
-        lists = _use_mask_lists(cfg, bias_mat)
+        lists = mlists is None and _use_mask_lists(cfg, bias_mat)
         present = None
-        if lists:
+        if mlists is not None:
+            _lib.call("gatmi_dense_attn_fwd_lists", B, N, H, dp, ptr(Wh), ptr(f1), ptr(f2), ptr(mlists.lptr), ptr(mlists.lcol),
+                      ptr(mlists.lord), mlists.max_fwd, ptr(biasp), ptr(res), _ACT[cfg.activation], cfg.slope,
+                      cfg.coef_keep, cfg.feat_keep, cfg.seed, ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), st)
+        elif lists:
             if agg is not None:      # visited-entry bits for the backward pass
                 present = torch.empty((B * N, _lib.lib.gatmi_dense_mask_words(N)), dtype=torch.int32, device=x.device)
             _lib.call("gatmi_dense_attn_fwd_masked", B, N, H, dp, ptr(Wh), ptr(f1), ptr(f2), ptr(bias_mat), ptr(biasp), ptr(res),
@@ -354,7 +369,7 @@ class DenseGATLayerFn(torch.autograd.Function):
                       _ACT[cfg.activation], cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
                       ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), st)
         if need_grad:
-            ctx.cfg, ctx.dims, ctx.present = cfg, (B, N), present
+            ctx.cfg, ctx.dims, ctx.present, ctx.mlists = cfg, (B, N), present, mlists
             ctx.has_bias, ctx.has_res = bias is not None, W_res is not None
             ctx.save_for_backward(x2, Wp, a1p, a2p, Wrp, Wh, f1, f2, out, agg, pos, lse, q, bias_mat, biasp)
         o = out.reshape(B, N, H, dp)
@@ -374,14 +389,17 @@ class DenseGATLayerFn(torch.autograd.Function):
         dbias = _new((hd,), x2)
         dWh = _new((n, hd), x2)
         df2 = _new((n, H), x2)
-        if ctx.present is not None and _lib.lib.gatmi_dense_attn_bwd_fused_ok(B, N, H, dp, cfg.coef_keep, cfg.feat_keep):
+        ml = ctx.mlists
+        if ml is not None or (ctx.present is not None and _lib.lib.gatmi_dense_attn_bwd_fused_ok(B, N, H, dp, cfg.coef_keep, cfg.feat_keep)):
             # batches of many small graphs: the block that owns a graph forms g, the row statistics and df1 of its
             # nodes while it stages them (no per-destination launch, no round trip of g / stats through memory)
             g = _new((n, hd), x2) if ctx.has_res else None          # only the residual branch reads g afterwards
             ws = _new((_lib.lib.gatmi_dense_attn_bwd_fused_ws_floats(B, H, dp),), x2)
+            lists = (None, None, None, 0) if ml is None else (ptr(ml.cptr), ptr(ml.crow), ptr(ml.cord), ml.max_bwd)
             _lib.call("gatmi_dense_attn_bwd_fused", B, N, H, dp, ptr(dout), ptr(out) if ctx.has_res else None, ptr(agg), ptr(pos),
                       ptr(q), ptr(f1), ptr(lse), ptr(biasp), _ACT[cfg.activation], ptr(Wh), ptr(f2), ptr(bias_mat), ptr(ctx.present),
-                      ptr(a1p), ptr(a2p), cfg.slope, ptr(g), ptr(df1), ptr(dbias), ptr(ws), ptr(dWh), ptr(df2), st)
+                      *lists, ptr(a1p), ptr(a2p), cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
+                      ptr(g), ptr(df1), ptr(dbias), ptr(ws), ptr(dWh), ptr(df2), st)
             dx, dW, da1, da2, db1, db2, dWr = _project_backward(x2, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
             if dx is not None:
                 dx = dx.reshape(B, N, -1)

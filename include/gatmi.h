@@ -377,20 +377,62 @@ int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int32_t dp,
 
 /* gatmi_gat_bwd_node and gatmi_dense_attn_bwd_masked in one launch, for the shapes the graph-resident list
  * kernels cover (batches of at least 256 graphs of 4..320 nodes, N % 4 == 0, rows of 64 floats, heads of at
- * least 8, no dropout: gatmi_dense_attn_bwd_fused_ok says 1): the block that owns a graph forms g, the row
- * statistics and df1 of its nodes while it stages them, so they make no round trip through memory and one
- * launch per step goes away.  Arguments as in those two calls; g may be NULL (it is only needed by a residual
- * branch), dbias may be NULL, ws: gatmi_dense_attn_bwd_fused_ws_floats(B, H, dp) floats when dbias is given.
- * Other shapes: GATMI_EUNSUPPORTED (use the two calls). */
+ * least 8; dropout of utils/layers.py:20,22 included: gatmi_dense_attn_bwd_fused_ok says 1): the block that owns
+ * a graph forms g, the row statistics and df1 of its nodes while it stages them, so they make no round trip
+ * through memory and one launch per step goes away.  Arguments as in those two calls; g may be NULL (it is only
+ * needed by a residual branch), dbias may be NULL, ws: gatmi_dense_attn_bwd_fused_ws_floats(B, H, dp) floats when
+ * dbias is given.  The structure of the mask comes EITHER from bias_mat + the forward pass's `present` bits
+ * (cptr = crow = cord = NULL) OR from prebuilt lists (cptr, crow, cord, max_entries from the calls below;
+ * bias_mat and present may then be NULL).  Other shapes: GATMI_EUNSUPPORTED (use the two calls). */
 int gatmi_dense_attn_bwd_fused_ok(int64_t B, int32_t N, int32_t H, int32_t dp, float coef_keep, float feat_keep);
 size_t gatmi_dense_attn_bwd_fused_ws_floats(int64_t B, int32_t H, int32_t dp);
 int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32_t dp,
                                const float *dout, const float *out, const float *agg, const float *pos,
                                const float *q, const float *f1, const float *lse, const float *bias, int32_t activation,
                                const float *Wh, const float *f2, const float *bias_mat, const uint32_t *present,
+                               const int32_t *cptr, const uint16_t *crow, const uint16_t *cord, int64_t max_entries,
                                const float *a1, const float *a2, float slope,
+                               float coef_keep, float feat_keep, uint64_t seed,
                                float *g, float *df1, float *dbias, float *ws,
                                float *dWh, float *df2, void *stream);
+
+/* A mask that stays the same step after step (the reference feeds one bias_mat every epoch,
+ * execute_cora.py:100-107; utils/layers.py:16-24 only ever adds it to the logits) need not be read and compacted
+ * again: its structure can be turned into lists once, and the graph-resident kernels then do nothing but walk them
+ * (no mask read, no compaction; rows are taken in the order of their list lengths so that the eight rows a wave
+ * walks together finish together).  For hard masks only: every visited entry of a row carries the row's maximum,
+ * so the bias cancels in the softmax (adj_to_bias masks, utils/process.py:14-25; gatmi_dense_mask_bits reports
+ * rows for which this does not hold in their flag word, and such masks stay with gatmi_dense_attn_fwd_masked).
+ *   gatmi_dense_mask_bits     bits [B*N, gatmi_dense_mask_words(N)]: bit j of row (b, i) = entry (i, j) is within
+ *                             1e6 of its row's maximum (the entries gatmi_dense_attn_fwd_masked visits); last
+ *                             word of a row = 1 when some visited entry differs from the row's maximum, or when
+ *                             several entries share a maximum beyond shared_limit in magnitude (fp32 then rounds
+ *                             the logits added to it: a row masked everywhere attends uniformly)
+ *   gatmi_dense_lists_count   row_cnt, col_cnt [B*N] int32: list lengths (visited columns of a row / visiting rows
+ *                             of a column), padded to whole batches of four
+ *   (caller)                  lptr, cptr [B*N + 1] int32 = exclusive prefix sums of the counts; lcol, crow: that
+ *                             many uint16, 8-byte aligned; lord / cord [B*N] uint16: per graph, its rows /
+ *                             columns ordered by list length, longest first; max_entries: the largest number of
+ *                             list entries one graph holds (forward: rows; backward: columns)
+ *   gatmi_dense_lists_fill    lcol, crow: the lists, padded with the id N, in the order in which the compacting
+ *                             kernels build theirs (results are bit-identical to the mask-reading kernels)
+ *   gatmi_dense_lists_capacity  list entries of one graph that fit beside its rows in LDS for this shape
+ *                             (backward != 0: for gatmi_dense_attn_bwd_fused); 0: shape not covered
+ *   gatmi_dense_attn_fwd_lists  gatmi_dense_attn_fwd_masked on the lists; GATMI_ERANGE when max_entries exceeds
+ *                             the capacity.  A caller that understates max_entries gets wrong rows for the graphs
+ *                             that exceed it, never an out-of-bounds access.
+ * Shapes: those of the graph-resident kernels (see gatmi_dense_attn_bwd_fused). */
+int gatmi_dense_mask_bits(int64_t B, int32_t N, const float *bias_mat, float shared_limit, uint32_t *bits, void *stream);
+int gatmi_dense_lists_count(int64_t B, int32_t N, const uint32_t *bits, int32_t *row_cnt, int32_t *col_cnt, void *stream);
+int gatmi_dense_lists_fill(int64_t B, int32_t N, const uint32_t *bits, const int32_t *lptr, const int32_t *cptr,
+                           uint16_t *lcol, uint16_t *crow, void *stream);
+int64_t gatmi_dense_lists_capacity(int32_t N, int32_t H, int32_t dp, int32_t backward);
+int gatmi_dense_attn_fwd_lists(int64_t B, int32_t N, int32_t H, int32_t dp,
+                               const float *Wh, const float *f1, const float *f2,
+                               const int32_t *lptr, const uint16_t *lcol, const uint16_t *lord, int64_t max_entries,
+                               const float *bias, const float *resid, int32_t activation, float slope,
+                               float coef_keep, float feat_keep, uint64_t seed,
+                               float *out, float *agg, float *pos, float *lse, float *q, void *stream);
 
 /* Brain-network variant of the attention step: the inner loop body of attn_e2v_BNF_V2
  * (utils/layers.py:174-179) with the coefficients of attn_v2e_BNF_V2 (:229-237), for H heads that

@@ -349,6 +349,106 @@ def test_graph_resident_kernels_for_batches_of_many_small_graphs(B, N, F, H, D, 
         assert_close(res["lists"][1][sl], rx.grad.numpy(), atol_scale=5e-6, what="graph-resident dX vs oracle")
 
 
+def test_graph_resident_parameter_gradients_against_the_oracle():
+    """Every gradient of the graph-resident kernels — dX, dW, da1, da2, db1, db2, dbias — against the float64 oracle
+    on a whole batch (256 graphs of 52 nodes: small enough for float64 on the host), hard and soft masks, without
+    going through the matrix-core kernels."""
+    from gat_amd import ops
+    dev = torch.device("cuda:0")
+    B, N, F, H, D = 256, 52, 6, 8, 8
+    for soft in (False, True):
+        bm = _masks(B, N, 0.12, 77, soft=soft).astype(np.float32)
+        p = layer_params(F, H, D, seed=31)
+        x = np.random.default_rng(32).normal(0, 1, (B, N, F)).astype(np.float32)
+        dout = np.random.default_rng(33).normal(0, 1, (B, N, H * D)).astype(np.float32)
+        tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+        xt = torch.tensor(x, device=dev, requires_grad=True)
+        out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], torch.tensor(bm, device=dev),
+                                  ops.make_cfg(H, D, "elu", mask_path="lists"))
+        out.backward(torch.tensor(dout, device=dev))
+        rp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+        rx = torch.tensor(x.astype(np.float64), requires_grad=True)
+        ref = ref_torch.layer_dense(rx, rp, torch.tensor(bm.astype(np.float64)), "elu", "concat")
+        ref.backward(torch.tensor(dout.astype(np.float64)))
+        assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), what="forward")
+        assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what="dX")
+        for k in ("W", "a1", "a2", "bias"):
+            assert_close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), atol_scale=5e-6, what="d" + k)
+        for k in ("b1", "b2"):          # sums of terms that cancel almost completely: tolerance relative to the sum of magnitudes
+            got, want = tp[k].grad.cpu().numpy().astype(np.float64), rp[k].grad.numpy()
+            assert np.all(np.abs(got - want) <= 1e-5 * np.abs(want) + 1e-6 * B * N * np.abs(dout).mean() * H), (k, got, want)
+
+
+@pytest.mark.parametrize("B,N,F,H,D,drops", [(256, 52, 6, 8, 8, (0.0, 0.0)), (260, 264, 8, 8, 8, (0.0, 0.0)), (300, 132, 7, 1, 64, (0.0, 0.0)),
+                                              (256, 8, 3, 4, 16, (0.0, 0.0)), (256, 72, 5, 4, 16, (0.6, 0.6)), (256, 52, 6, 8, 8, (0.5, 0.0))])
+def test_prebuilt_lists_equal_the_mask_reading_kernels_bit_for_bit(B, N, F, H, D, drops):
+    """MaskLists (the lists of an unchanging mask, built once) through the graph-resident kernels: the lists hold the
+    entries the mask-reading kernels visit, in the order in which those compact them, so forward, every gradient and
+    the dropout masks must be bit-identical to the run that reads the mask."""
+    from gat_amd import ops
+    from gat_amd.graph import MaskLists
+    dev = torch.device("cuda:0")
+    bm = torch.tensor(_masks(B, N, 0.1, 11 + N).astype(np.float32), device=dev)
+    ml = MaskLists(bm)
+    assert ml.fits(H, ops.padded_width(D)) and ml.entries >= int((bm == 0).sum()) and ml.max_fwd % 4 == 0
+    p = layer_params(F, H, D, seed=N)
+    x = np.random.default_rng(N + 1).normal(0, 1, (B, N, F)).astype(np.float32)
+    dout = torch.tensor(np.random.default_rng(N + 2).normal(0, 1, (B, N, H * D)).astype(np.float32), device=dev)
+    res = []
+    for mask in (bm, ml):
+        tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+        xt = torch.tensor(x, device=dev, requires_grad=True)
+        cfg = ops.make_cfg(H, D, "elu", coef_drop=drops[0], in_drop=drops[1], training=True, seed=4242, mask_path="lists")
+        out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], mask, cfg)
+        out.backward(dout)
+        res.append([out.detach(), xt.grad] + [tp[k].grad for k in ("W", "a1", "a2", "b1", "b2", "bias")])
+    torch.cuda.synchronize()
+    for a, b, name in zip(res[0], res[1], ("out", "dX", "dW", "da1", "da2", "db1", "db2", "dbias")):
+        assert torch.equal(a, b), "prebuilt lists vs mask: %s differs (max %g)" % (name, float((a - b).abs().max()))
+    assert float(res[1][0].abs().max()) > 0
+
+
+def test_prebuilt_lists_refuse_masks_whose_biases_matter():
+    from gat_amd.graph import MaskLists
+    dev = torch.device("cuda:0")
+    hard = _masks(256, 16, 0.2, 3).astype(np.float32)
+    MaskLists(torch.tensor(hard, device=dev))
+    soft = _masks(256, 16, 0.2, 3, soft=True).astype(np.float32)
+    with pytest.raises(ValueError):
+        MaskLists(torch.tensor(soft, device=dev))
+    everywhere = hard.copy()
+    everywhere[200, 5, :] = -1e9                               # a row masked everywhere: fp32 swallows its logits
+    with pytest.raises(ValueError):
+        MaskLists(torch.tensor(everywhere, device=dev))
+    with pytest.raises(ValueError):
+        MaskLists(torch.tensor(hard[:, :15, :15].copy(), device=dev))      # N not a multiple of 4
+
+
+def test_mask_memo_switches_a_batch_of_small_graphs_to_prebuilt_lists():
+    """GATHeads on one unchanged [B,N,N] mask tensor: the first call reads the mask, the second builds the lists,
+    every later call walks them; all calls give the same bits, and a changed mask drops the memo entry."""
+    from gat_amd import layers
+    from gat_amd.graph import MaskLists
+    dev = torch.device("cuda:0")
+    B, N, F, H, D = 256, 40, 7, 8, 8
+    bt = torch.tensor(_masks(B, N, 0.1, 5).astype(np.float32), device=dev)
+    m = layers.GATHeads(F, H, D, device=dev)
+    m.load(layer_params(F, H, D, seed=9))
+    x = torch.randn(B, N, F, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    layers.mask_graphs._entries.clear()
+    calls = [m(x, bt, "elu").detach().clone() for _ in range(4)]
+    assert isinstance(layers.mask_graphs.lookup(bt, (H, D)), MaskLists)
+    for c in calls[1:]:
+        assert torch.equal(c, calls[0])
+    narrow = layers.GATHeads(F, 1, 7, device=dev)                # rows of 8 floats: not a shape of the graph-resident kernels
+    narrow(x, bt, "identity")
+    assert isinstance(layers.mask_graphs.lookup(bt, (1, 8)), layers.CSRGraph)
+    bt[0, 0, 1] = 0.0 if float(bt[0, 0, 1]) != 0.0 else -1e9    # in-place change: the version counter moves
+    changed = m(x, bt, "elu")
+    assert not torch.equal(changed, calls[0])
+    assert torch.equal(changed, m(x, bt, "elu")) and torch.equal(changed, m(x, bt, "elu"))
+
+
 @pytest.mark.parametrize("B,N,F,H,D", [(256, 52, 6, 8, 8), (270, 100, 9, 4, 16)])
 def test_graph_resident_kernels_with_a_residual_projection(B, N, F, H, D):
     """The residual branch (utils/layers.py:28-32, widths differ: a second projection with bias) through the

@@ -80,11 +80,13 @@ def test_rate_zero_and_eval_are_exact_identities():
 
 
 @pytest.mark.parametrize("path", ["dense", "lists"])
-@pytest.mark.parametrize("B,N,H,D,coef_drop,in_drop", [(2, 60, 8, 8, 0.6, 0.6), (1, 700, 8, 8, 0.5, 0.3), (3, 33, 1, 7, 0.4, 0.0)])
+@pytest.mark.parametrize("B,N,H,D,coef_drop,in_drop", [(2, 60, 8, 8, 0.6, 0.6), (1, 700, 8, 8, 0.5, 0.3), (3, 33, 1, 7, 0.4, 0.0),
+                                                       (256, 28, 8, 8, 0.6, 0.6), (257, 20, 2, 32, 0.3, 0.5), (256, 24, 4, 16, 0.0, 0.6)])
 def test_dense_layer_masks_replay(B, N, H, D, coef_drop, in_drop, path):
     """Same check for the dense kernels (the LDS-resident and the chunked matrix-core variants, and
     the compacted-list kernels, which draw the very same masks): masks are
-    keyed on (graph, i, j, head) and (graph, j, padded column)."""
+    keyed on (graph, i, j, head) and (graph, j, padded column).  Batches of 256 graphs and more take the
+    graph-resident list kernels, dropout included (the feature mask is applied once per row while a graph is staged)."""
     from gat_amd import ops
     if path == "lists" and H * ops.padded_width(D) < 32:
         pytest.skip("the list kernels take rows of at least 32 floats")
