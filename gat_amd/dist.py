@@ -596,7 +596,7 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             ctx.pgraph, ctx.cfg, ctx.has_bias, ctx.replicate, ctx.overlap = pgraph, cfg, bias is not None, replicate, overlap
             ctx.save_for_backward(x, Wp, a1p, a2p, feat, f1, f2, b2c, out, agg, pos, lse, q, biasp)
         if cfg.reduce == "mean":
-            return out[:, :D] if D != dp else out
+            return out                                   # padded rows [n, dp]; dist_sparse_gat_layer slices (see ops.SparseGATLayerFn)
         return out.reshape(n, H, dp)[:, :, :D].reshape(n, H * D) if D != dp else out
 
     @staticmethod
@@ -610,7 +610,7 @@ class DistSparseGATLayerFn(torch.autograd.Function):
         replicate = ctx.replicate
         st = _lib.current_stream()
         if cfg.reduce == "mean":
-            dout = ops._pad_last(dout, D, dp)
+            dout = dout.contiguous()
         else:
             dout = ops._pad_last(dout.reshape(n, H, D), D, dp).reshape(n, hd)
         bf16 = cfg.storage == "bf16"
@@ -691,7 +691,10 @@ def dist_sparse_gat_layer(x, W, a1, a2, b1, b2, bias, pgraph, cfg, halo="exchang
         raise ValueError("halo must be 'exchange' or 'replicate'")
     if overlap not in (True, False, "off", "pipeline", "two_phase"):
         raise ValueError("overlap must be False / 'off', True / 'pipeline' or 'two_phase'")
-    return DistSparseGATLayerFn.apply(x, W, a1, a2, b1, b2, bias, pgraph, cfg, halo == "replicate", overlap)
+    out = DistSparseGATLayerFn.apply(x, W, a1, a2, b1, b2, bias, pgraph, cfg, halo == "replicate", overlap)
+    if cfg.reduce == "mean" and cfg.D != cfg.dp:
+        out = out[:, :cfg.D]
+    return out
 
 
 def allreduce_grads(params, group=None):

@@ -16,7 +16,7 @@ TensorFlow create variables on the way; here the variables come from the active 
 """
 import torch
 
-from . import layers
+from . import layers, ops
 
 
 class TFAdam(torch.optim.Optimizer):
@@ -107,8 +107,16 @@ class BaseGAttN:
         return -(labels * torch.log_softmax(logits, dim=-1)).sum(-1).mean(0)
 
     @staticmethod
+    def _fused_ce(logits, labels):
+        return (logits.is_cuda and logits.dim() == 2 and logits.dtype == torch.float32 and labels.dtype == torch.float32
+                and logits.shape[1] <= 256 and labels.shape == logits.shape)
+
+    @staticmethod
     def masked_softmax_cross_entropy(logits, labels, mask):
-        """base_gattn.py:140-146: per-node CE weighted by mask / mean(mask), mean over ALL nodes."""
+        """base_gattn.py:140-146: per-node CE weighted by mask / mean(mask), mean over ALL nodes.  On the GPU one
+        sweep over the logits gives the loss and its gradient (ops.masked_cross_entropy)."""
+        if BaseGAttN._fused_ce(logits, labels):
+            return ops.masked_cross_entropy(logits, labels, mask)[0]
         loss = -(labels * torch.log_softmax(logits, dim=-1)).sum(-1)
         mask = mask.to(loss.dtype)
         return (loss * (mask / mask.mean())).mean()
@@ -116,9 +124,18 @@ class BaseGAttN:
     @staticmethod
     def masked_accuracy(logits, labels, mask):
         """base_gattn.py:158-165."""
+        if BaseGAttN._fused_ce(logits, labels):
+            return ops.masked_cross_entropy(logits.detach(), labels, mask)[1]
         correct = (logits.argmax(1) == labels.argmax(1)).to(torch.float32)
         mask = mask.to(torch.float32)
         return (correct * (mask / mask.mean())).mean()
+
+    @staticmethod
+    def masked_loss_and_accuracy(logits, labels, mask):
+        """The two quantities the drivers evaluate every epoch (execute_cora.py:74-75) from ONE sweep."""
+        if BaseGAttN._fused_ce(logits, labels):
+            return ops.masked_cross_entropy(logits, labels, mask)
+        return BaseGAttN.masked_softmax_cross_entropy(logits, labels, mask), BaseGAttN.masked_accuracy(logits, labels, mask)
 
     @staticmethod
     def accuracy(preds, labels):

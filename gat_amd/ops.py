@@ -195,7 +195,10 @@ class SparseGATLayerFn(torch.autograd.Function):
             ctx.sparse_x = x if sparse_x else None
             ctx.save_for_backward(x.val if sparse_x else x, Wp, a1p, a2p, Wrp, Wh, f1, f2, b2c, out, agg, pos, lse, q, biasp)
         if cfg.reduce == "mean":
-            return out[:, :D] if D != dp else out
+            # the averaged head in its padded rows [n, dp]: sparse_gat_layer slices the padding off OUTSIDE this
+            # function, so that the result is a view whose base is this tensor and a fused loss can read the padded
+            # rows and hand back a gradient of the same layout (no padding pass in either direction)
+            return out
         return out.reshape(n, H, dp)[:, :, :D].reshape(n, H * D) if D != dp else out
 
     @staticmethod
@@ -209,7 +212,7 @@ class SparseGATLayerFn(torch.autograd.Function):
         n = x.shape[0]
         st = _lib.current_stream()
         if cfg.reduce == "mean":
-            dout = _pad_last(dout, D, dp)
+            dout = dout.contiguous()                     # [n, dp]: the forward pass returned the padded rows
         else:
             dout = _pad_last(dout.reshape(n, H, D), D, dp).reshape(n, hd)
         bf16 = cfg.storage == "bf16"
@@ -459,7 +462,66 @@ def make_cfg(H, D, activation="elu", reduce="concat", coef_drop=0.0, in_drop=0.0
 
 
 def sparse_gat_layer(x, W, a1, a2, b1, b2, bias, graph, cfg, W_res=None, b_res=None):
-    return SparseGATLayerFn.apply(x, W, a1, a2, b1, b2, bias, W_res, b_res, graph, cfg)
+    out = SparseGATLayerFn.apply(x, W, a1, a2, b1, b2, bias, W_res, b_res, graph, cfg)
+    if cfg.reduce == "mean" and cfg.D != cfg.dp:
+        out = out[:, :cfg.D]                             # a view of the padded rows (see SparseGATLayerFn.forward)
+    return out
+
+
+def padded_base(logits, C):
+    """(tensor, row stride) under which a fused loss can read `logits` [n, C] in place: when it is the leading C
+    columns of a contiguous [n, ld] tensor it was sliced from (the averaged head of sparse_gat_layer: ld = padded
+    width), that tensor — an autograd node itself, so the gradient can go to it directly, in its own layout —
+    otherwise the logits made contiguous."""
+    base = logits._base
+    if (base is not None and base.dim() == 2 and base.is_contiguous() and logits.dim() == 2 and base.shape[0] == logits.shape[0]
+            and logits.data_ptr() == base.data_ptr() and logits.stride() == (base.shape[1], 1)
+            and C <= base.shape[1] <= padded_width(C) and base.dtype == logits.dtype):
+        return base
+    return logits.contiguous()
+
+
+class MaskedCrossEntropyFn(torch.autograd.Function):
+    """models/base_gattn.py:140-146 and :158-165 in one sweep (gatmi_masked_ce): (loss, accuracy) of logits [n, ld]
+    whose first C columns count, labels [n, C] (one-hot or soft), mask [n] floats or None.  The gradient of the loss
+    is formed in the same sweep and handed back in the logits' own layout."""
+
+    @staticmethod
+    def forward(ctx, logits, C, labels, mask):
+        _require_cuda(logits, labels, mask)
+        logits, labels = _f32(logits).contiguous(), _f32(labels).contiguous()
+        n, ld = logits.shape
+        if tuple(labels.shape) != (n, C) or (mask is not None and tuple(mask.shape) != (n,)):
+            raise ValueError("masked cross-entropy: logits [%d,%d(%d)], labels %s, mask %s" % (n, C, ld, tuple(labels.shape), None if mask is None else tuple(mask.shape)))
+        if mask is not None:
+            mask = mask.to(torch.float32).contiguous()
+        need = ctx.needs_input_grad[0]
+        dl = torch.empty_like(logits) if need else None
+        out3 = _new((3,), logits)
+        ws = _new((_lib.lib.gatmi_masked_ce_ws_floats(),), logits)
+        _lib.call("gatmi_masked_ce", n, C, ptr(logits), ld, ptr(labels), C, ptr(mask), ptr(dl), ptr(out3), ptr(ws), _lib.current_stream())
+        if need:
+            ctx.save_for_backward(dl)
+            ctx.scaled = False
+        loss, acc = out3[0], out3[1]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, gl, _ga):
+        (dl,) = ctx.saved_tensors
+        if ctx.scaled:                                   # a second sweep over the same tape: the saved rows were scaled in place
+            raise RuntimeError("masked cross-entropy: backward through the same forward pass twice is not supported")
+        ctx.scaled = True
+        gl = gl.to(torch.float32).contiguous()
+        _lib.call("gatmi_scale_by_device_scalar", ptr(dl), dl.numel(), ptr(gl), _lib.current_stream())
+        return dl, None, None, None
+
+
+def masked_cross_entropy(logits, labels, mask=None):
+    """(loss, accuracy) as 0-dim tensors; logits [n, C] on the GPU."""
+    C = logits.shape[-1]
+    return MaskedCrossEntropyFn.apply(padded_base(logits, C), C, labels, mask)
 
 
 def dense_gat_layer(x, W, a1, a2, b1, b2, bias, bias_mat, cfg, W_res=None, b_res=None):

@@ -434,6 +434,24 @@ int gatmi_dense_attn_fwd_lists(int64_t B, int32_t N, int32_t H, int32_t dp,
                                float coef_keep, float feat_keep, uint64_t seed,
                                float *out, float *agg, float *pos, float *lse, float *q, void *stream);
 
+/* Masked softmax cross-entropy, its gradient and the masked accuracy in one sweep over the logits
+ * (models/base_gattn.py:140-146 masked_softmax_cross_entropy, :158-165 masked_accuracy; called at
+ * execute_cora.py:74-75):
+ *     loss     = mean_i(CE_i * mask_i / mean(mask)),  CE_i = -sum_c labels[i,c] * log_softmax(logits[i,:])[c]
+ *     accuracy = mean_i([argmax logits[i,:] == argmax labels[i,:]] * mask_i / mean(mask))
+ *     dlogits[i,c] = mask_i / sum(mask) * (softmax(logits[i,:])[c] * sum_c' labels[i,c'] - labels[i,c])
+ *   logits [n, C] with row stride ld_logits floats (the layer's padded rows are fine: only C columns are read),
+ *   labels [n, C] one-hot or soft, row stride ld_labels; mask [n] floats or NULL (all ones); C <= 256.
+ *   dlogits (may be NULL) has the layout of logits; its columns C .. ld_logits - 1 are set to zero, so it can be
+ *   handed to the layer's backward pass as it is (ld_logits at most the padded width of C).
+ *   out3 = {loss, accuracy, sum(mask)} in DEVICE memory; ws: gatmi_masked_ce_ws_floats() floats.
+ * All sums run in a fixed order.  gatmi_scale_by_device_scalar multiplies x[0..n) (n % 4 == 0) by *scale, a float
+ * in device memory, and does nothing when it is exactly 1: the upstream gradient of a loss. */
+size_t gatmi_masked_ce_ws_floats(void);
+int gatmi_masked_ce(int64_t n, int32_t C, const float *logits, int64_t ld_logits, const float *labels, int64_t ld_labels,
+                    const float *mask, float *dlogits, float *out3, float *ws, void *stream);
+int gatmi_scale_by_device_scalar(float *x, int64_t n, const float *scale, void *stream);
+
 /* Brain-network variant of the attention step: the inner loop body of attn_e2v_BNF_V2
  * (utils/layers.py:174-179) with the coefficients of attn_v2e_BNF_V2 (:229-237), for H heads that
  * share X and the weighted adjacency A but own their projection (f1, f2) and the scalars m1, m2
