@@ -100,6 +100,16 @@ def main():
         cl, halo, counts = gdist.halo_plan_device(part, 0, src)
         remote = float((src >= n_own).sum()) / src.numel()
         n_halo = int(halo.numel())
+        # What replicating hub rows on every rank could save: halo rows by the number of this shard's entries that read
+        # them.  The bytes of an exchange are proportional to ROWS; hubs carry the entries, not the rows.
+        refs = torch.bincount(cl[cl >= n_own].to(torch.int64) - n_own, minlength=n_halo)
+        n_remote = int(refs.sum())
+        hub_table = {}
+        for t in (2, 4, 16, 64, 256, 1024):
+            sel = refs >= t
+            hub_table["refs>=%d" % t] = {"halo_rows": int(sel.sum()), "share_of_halo_rows": round(float(sel.sum()) / max(1, n_halo), 4),
+                                          "share_of_remote_entries": round(float(refs[sel].sum()) / max(1, n_remote), 4)}
+        del refs
         g = CSRGraph.from_device_coo(dst, cl.to(torch.int64), n_own, n_own + n_halo, chunk=0)
         del dst, src, cl
         pg = gdist.PartitionedGraph(g, _NoPeers(n_own, n_halo), part, 0)
@@ -122,7 +132,7 @@ def main():
             step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 10 * 1e3
-        line = {"world": world, "entries": g.nnz, "remote_entry_frac": round(remote, 3), "n_halo": n_halo,
+        line = {"world": world, "entries": g.nnz, "remote_entry_frac": round(remote, 3), "n_halo": n_halo, "halo_rows_by_reference_count": hub_table,
                 "exchange_MB_forward_f32": round(n_halo * 256 / 1e6), "exchange_MB_backward_f32": round(n_halo * 288 / 1e6), "replicated_input_MB": round(n_halo * F * 4 / 1e6),
                 "replicate_step_ms": round(ms, 3), "edges_per_s_per_gpu": round(g.nnz / ms * 1e3)}
         if world > 1:
