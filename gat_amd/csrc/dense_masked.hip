@@ -609,16 +609,14 @@ struct MRowState8 {
 // column 0 of this lane's (row, head), an entry's index is cbase + j * H.  Feature dropout (:22) needs nothing here:
 // the rows in LDS were dropped when they were staged.
 template <int LPH8, bool SAVE, bool SOFT, bool DROP>
-__device__ __forceinline__ void graph_fwd_batch8(MRowState8 &st, float slope, const uint16_t *lp, const float *bm, int N,
-                                                 const float *whs, const float *f2s, float f1v,
-                                                 uint64_t seed, uint64_t cbase, float coef_keep) {
+__device__ __forceinline__ void graph_fwd_batch8_ids(MRowState8 &st, float slope, const int (&j)[kGraphBatch], const float *bm, int N,
+                                                     const float *whs, const float *f2s, float f1v,
+                                                     uint64_t seed, uint64_t cbase, float coef_keep) {
     constexpr int H = 8 / LPH8;
     constexpr int HD = 64;
     constexpr int U = kGraphBatch;
-    int j[U];
     float z[U], e[U];
     float4 v0[U], v1[U];
-    load_ids<U>(lp, j);
 #pragma unroll
     for (int t = 0; t < U; ++t) {
         z[t] = f1v + f2s[j[t] * H];
@@ -666,6 +664,15 @@ __device__ __forceinline__ void graph_fwd_batch8(MRowState8 &st, float slope, co
     st.m = mn;
 }
 
+template <int LPH8, bool SAVE, bool SOFT, bool DROP>
+__device__ __forceinline__ void graph_fwd_batch8(MRowState8 &st, float slope, const uint16_t *lp, const float *bm, int N,
+                                                 const float *whs, const float *f2s, float f1v,
+                                                 uint64_t seed, uint64_t cbase, float coef_keep) {
+    int j[kGraphBatch];
+    load_ids<kGraphBatch>(lp, j);
+    graph_fwd_batch8_ids<LPH8, SAVE, SOFT, DROP>(st, slope, j, bm, N, whs, f2s, f1v, seed, cbase, coef_keep);
+}
+
 constexpr int kGraphWalkRows = 8;          // rows per wave in the eight-lane walk
 constexpr int kGraph8MaxWaves = 12;        // three waves per SIMD: 168 registers per lane (two mask rows + the walk state)
 
@@ -703,8 +710,9 @@ __device__ __forceinline__ void stage_graph_lists(int64_t b, int N, const int32_
 // graph's rows, a wave takes the rows eight at a time in the order of their list lengths (rows of one octet finish
 // together), and what remains is the walk.  DROP: dropout of utils/layers.py:20,22 from the counter hashes, the
 // feature mask applied once per row while the graph is staged.
-template <int LPH8, bool SAVE, bool LISTS, bool DROP>
+template <int LPH8, bool SAVE, bool DROP>
 __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_fwd8_kernel(MaskedFwdArgs a, int lc) {
+    constexpr bool LISTS = false;          // (the walk-only form of this kernel is dense_graph_fwd8_lists_kernel)
     constexpr int G = 16;                  // compaction: lanes per row
     constexpr int H = 8 / LPH8;
     constexpr int HD = 64;
@@ -882,6 +890,147 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_fwd8_kernel(
             store_stream4(o, r0);
             store_stream4(o + 4, r1);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The walk alone, on prebuilt lists (gatmi_dense_lists_fill): no mask read, no compaction.  The lists are not
+// staged either: a row's eight lanes fetch 32 of its entries with one 8-byte load each, straight from memory,
+// and hand them round with ds_bpermute; the next octet's entries are requested before the current octet is
+// walked.  LDS then holds only the graph's rows (Wh, f2), the list offsets and the row order — under 80 KB
+// at 264 nodes, so that TWO blocks share a CU and one block's staging and stores overlap the other's walk
+// (a block alone alternates between a memory phase and an arithmetic phase).  Rows are taken in the order of
+// their list lengths: the eight rows of an octet finish together.
+// ------------------------------------------------------------------------------------------
+constexpr int kGraph8ListsWaves = 8;       // two blocks per CU: four waves per SIMD, 128 registers per lane
+static inline int graph8_lists_waves(int N) {
+    const int octs = (N + kGraphWalkRows - 1) / kGraphWalkRows;
+    const int rounds = (octs + kGraph8ListsWaves - 1) / kGraph8ListsWaves;
+    return (octs + rounds - 1) / rounds;
+}
+// LDS: Wh [N + pad][64] | f2 [N + pad][H] | list offsets [N + 1 -> even] (int) | row order [N -> multiple of 4] (uint16)
+static inline size_t graph8_fwd_walk_lds(int N, int H) {
+    return (size_t)(N + kGraphPadRows) * (64 + H) * sizeof(float) + graph8_lists_head_lds(N);
+}
+
+template <int LPH8, bool SAVE, bool DROP>
+__global__ __launch_bounds__(64 * kGraph8ListsWaves, 2) void dense_graph_fwd8_lists_kernel(MaskedFwdArgs a) {
+    constexpr int H = 8 / LPH8;
+    constexpr int HD = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char graph_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int N = a.N;
+    const int NP = N + kGraphPadRows;
+    const int64_t b = blockIdx.x;
+    float *whs = reinterpret_cast<float *>(graph_smem);
+    float *f2s = whs + NP * HD;
+    int *off_s = reinterpret_cast<int *>(f2s + NP * H);
+    uint16_t *ord_s = reinterpret_cast<uint16_t *>(off_s + ((N + 2) & ~1));
+    const uint64_t seed = DROP ? seed_now(a) : 0;
+    const int32_t base = a.lptr[b * N];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.Wh + b * N * (int64_t)HD);
+        for (int e = threadIdx.x; e < NP * (HD / 4); e += blockDim.x) {
+            float4 v = e < N * (HD / 4) ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (DROP) {
+                if (a.feat_keep < 1.f) v = drop_feat(v, seed, b * N + (e >> 4), HD, (e & 15) * 4, a.feat_keep);
+            }
+            reinterpret_cast<float4 *>(whs)[e] = v;
+        }
+        const float *src2 = a.f2 + b * N * (int64_t)H;
+        for (int e = threadIdx.x; e < NP * H; e += blockDim.x) f2s[e] = e < N * H ? src2[e] : -INFINITY;
+        for (int r = threadIdx.x; r <= N; r += blockDim.x) off_s[r] = a.lptr[b * N + r] - base;
+        for (int r = threadIdx.x; r < N; r += blockDim.x) ord_s[r] = a.lord[b * N + r];
+    }
+    __syncthreads();
+    const int r8 = lane >> 3, s8 = lane & 7;
+    const int head8 = s8 / LPH8;
+    const float *whl = whs + s8 * 8;
+    const float *f2l = f2s + head8;
+    const uint16_t *gcol = a.lcol + base;
+    const uint32_t dummy = (uint32_t)N | ((uint32_t)N << 16);      // the zero row (Wh = 0, f2 = -inf: coefficient exactly 0)
+    const int lane0 = lane & 56;                                    // first lane of this row's group
+    // entries 4 s8 .. 4 s8 + 3 of chunk c0 of a row's list (a whole batch each); past the list: the dummy id.  The
+    // load is unconditional (clamped inside the list) so that the request for the NEXT octet can stay in flight
+    // across the walk of the current one.
+    auto fetch = [&](int o0, int total, int c0) -> uint2 {
+        const int at = c0 + 4 * s8;
+        const uint2 v = *reinterpret_cast<const uint2 *>(gcol + o0 + min(at, max(total - 4, 0)));
+        return at < total ? v : make_uint2(dummy, dummy);
+    };
+    auto octet = [&](int oct, int &i, int &o0, int &total) {
+        i = ord_s[min(oct + r8, N - 1)];
+        o0 = off_s[i];
+        total = oct + r8 < N ? off_s[i + 1] - o0 : 0;
+    };
+    int oct0 = wave * kGraphWalkRows;
+    int i = 0, o0 = 0, total = 0;
+    uint2 ch = make_uint2(dummy, dummy);
+    if (oct0 < N) {
+        octet(oct0, i, o0, total);
+        ch = fetch(o0, total, 0);
+    }
+    for (; oct0 < N; oct0 += nwaves * kGraphWalkRows) {
+        const int octn = oct0 + nwaves * kGraphWalkRows;
+        int in, on, tn;
+        octet(min(octn, N - 1), in, on, tn);                        // past the graph: the clamped row, never walked
+        if (octn >= N) tn = 0;
+        const uint2 chn = fetch(on, tn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool row_ok = oct0 + r8 < N;
+        const float f1v = a.f1[(b * N + i) * H + head8];
+        const uint64_t cbase = DROP ? ((uint64_t)(b * N + i) * (uint64_t)N) * H + head8 : 0;
+        MRowState8 st;
+        st.m = -INFINITY;
+        st.s = st.q = 0.f;
+        st.acc0 = st.acc1 = st.pos0 = st.pos1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c0 = 0; __any(c0 < total); c0 += 32) {
+            if (c0 > 0) ch = fetch(o0, total, c0);                  // lists of more than 32 entries: further chunks as they come
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (!__any(c0 + 4 * t < total)) break;              // wave-uniform
+                const uint32_t w0 = (uint32_t)__shfl((int)ch.x, lane0 + t, 64), w1 = (uint32_t)__shfl((int)ch.y, lane0 + t, 64);
+                const int j[kGraphBatch] = {(int)(w0 & 0xffff), (int)(w0 >> 16), (int)(w1 & 0xffff), (int)(w1 >> 16)};
+                graph_fwd_batch8_ids<LPH8, SAVE, false, DROP>(st, a.slope, j, nullptr, N, whl, f2l, f1v, seed, cbase, a.coef_keep);
+            }
+        }
+        if (row_ok) {
+            const int64_t row = b * N + i;
+            const bool empty = !(st.s > 0.f);
+            const float inv = empty ? 0.f : 1.0f / st.s;
+            const float4 ag0 = f4_scale(inv, st.acc0), ag1 = f4_scale(inv, st.acc1);
+            float *o = nullptr;
+            if (SAVE) {
+                o = a.agg + row * HD + s8 * 8;
+                store_stream4(o, ag0);
+                store_stream4(o + 4, ag1);
+                o = a.pos + row * HD + s8 * 8;
+                store_stream4(o, f4_scale(inv, st.pos0));
+                store_stream4(o + 4, f4_scale(inv, st.pos1));
+                if (s8 % LPH8 == 0) {
+                    a.lse[row * H + head8] = empty ? 0.f : st.m + logf(st.s);
+                    a.q[row * H + head8] = st.q * inv;
+                }
+            }
+            float4 r0 = ag0, r1 = ag1;
+            if (a.bias) {
+                r0 = f4_add(r0, *reinterpret_cast<const float4 *>(a.bias + s8 * 8));
+                r1 = f4_add(r1, *reinterpret_cast<const float4 *>(a.bias + s8 * 8 + 4));
+            }
+            if (a.resid) {
+                r0 = f4_add(r0, *reinterpret_cast<const float4 *>(a.resid + row * HD + s8 * 8));
+                r1 = f4_add(r1, *reinterpret_cast<const float4 *>(a.resid + row * HD + s8 * 8 + 4));
+            }
+            if (a.activation != GATMI_ACT_IDENTITY) {
+                r0 = make_float4(act_f(r0.x, a.activation), act_f(r0.y, a.activation), act_f(r0.z, a.activation), act_f(r0.w, a.activation));
+                r1 = make_float4(act_f(r1.x, a.activation), act_f(r1.y, a.activation), act_f(r1.z, a.activation), act_f(r1.w, a.activation));
+            }
+            o = a.out + row * HD + s8 * 8;
+            store_stream4(o, r0);
+            store_stream4(o + 4, r1);
+        }
+        i = in; o0 = on; total = tn; ch = chn;
     }
 }
 
@@ -1681,14 +1830,34 @@ static bool graph8_shape(int64_t B, int32_t N, int G, int LPH) {
     return G == 16 && LPH >= 2 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && B <= 0x7fffffff;
 }
 
-template <bool LISTS>
 static int launch_graph_fwd8(const MaskedFwdArgs &a, int LPH, bool save, bool drop, size_t lds, int lc, hipStream_t st, const char *name) {
     const int waves = graph8_waves(a.N);
     hipError_t e = hipSuccess;
 #define GATMI_L(ll, sv, dr)                                                                                          \
     {                                                                                                                \
-        if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_fwd8_kernel<ll, sv, LISTS, dr>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_fwd8_kernel<ll, sv, LISTS, dr>), dim3((unsigned)a.B), dim3(64 * waves), lds, st, a, lc); \
+        if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_fwd8_kernel<ll, sv, dr>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_fwd8_kernel<ll, sv, dr>), dim3((unsigned)a.B), dim3(64 * waves), lds, st, a, lc); \
+    }
+#define X(ll)                                                                                                        \
+    if (LPH == 2 * ll) {                                                                                            \
+        if (drop) GATMI_L(ll, true, true) else if (save) GATMI_L(ll, true, false) else GATMI_L(ll, false, false)     \
+        if (e != hipSuccess) return fail(GATMI_EHIP, "%s: %s", name, hipGetErrorString(e));                         \
+        GATMI_LAUNCH_CHECK(name);                                                                                   \
+        return GATMI_OK;                                                                                            \
+    }
+    X(1) X(2) X(4) X(8)
+#undef X
+#undef GATMI_L
+    return fail(GATMI_EUNSUPPORTED, "%s: no kernel for %d lanes per head", name, LPH);
+}
+
+static int launch_graph_fwd8_lists(const MaskedFwdArgs &a, int LPH, bool save, bool drop, size_t lds, hipStream_t st, const char *name) {
+    const int waves = graph8_lists_waves(a.N);
+    hipError_t e = hipSuccess;
+#define GATMI_L(ll, sv, dr)                                                                                          \
+    {                                                                                                                \
+        if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_fwd8_lists_kernel<ll, sv, dr>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_fwd8_lists_kernel<ll, sv, dr>), dim3((unsigned)a.B), dim3(64 * waves), lds, st, a); \
     }
 #define X(ll)                                                                                                        \
     if (LPH == 2 * ll) {                                                                                            \
@@ -1766,7 +1935,7 @@ extern "C" int gatmi_dense_attn_fwd_masked(int64_t B, int32_t N, int32_t H, int3
     const int lc = graph_list_capacity(N);
     if (graph8_shape(B, N, G, LPH) && graph8_fwd_lds(N, H, lc, graph8_waves(N)) <= graph_lds_limit()) {
         a.lptr = nullptr; a.lcol = a.lord = nullptr; a.lcap = 0;
-        return launch_graph_fwd8<false>(a, LPH, save, drop, graph8_fwd_lds(N, H, lc, graph8_waves(N)), lc, st, "dense_attn_fwd_masked (graph-resident, eight-lane walk)");
+        return launch_graph_fwd8(a, LPH, save, drop, graph8_fwd_lds(N, H, lc, graph8_waves(N)), lc, st, "dense_attn_fwd_masked (graph-resident, eight-lane walk)");
     }
     if (!drop && G == 16 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && graph_fwd_lds(N, G, H, lc) <= graph_lds_limit()) {
         const size_t lds = graph_fwd_lds(N, G, H, lc);
@@ -1888,8 +2057,10 @@ extern "C" size_t gatmi_dense_attn_bwd_fused_ws_floats(int64_t B, int32_t H, int
 
 extern "C" int64_t gatmi_dense_lists_capacity(int32_t N, int32_t H, int32_t dp, int32_t backward) {
     if (H <= 0 || dp < 8 || !is_pow2(dp) || !is_pow2(H) || H * dp != 64 || N < 4 || (N & 3) || N > kGraphMaxN) return 0;
-    const size_t fixed = backward ? graph8_bwd_lists_lds(N, H, 0, 0) : graph8_fwd_lists_lds(N, H, 0);
     const size_t limit = graph_lds_limit();
+    if (!backward)                                       // the forward kernel reads its lists from memory: any length, if the rows fit
+        return graph8_fwd_walk_lds(N, H) <= limit ? (int64_t)(N + kGraphBatch) * N : 0;
+    const size_t fixed = graph8_bwd_lists_lds(N, H, 0, 0);
     if (fixed + 64 >= limit) return 0;
     return (int64_t)((limit - fixed) / sizeof(uint16_t)) & ~(int64_t)3;
 }
@@ -1971,7 +2142,7 @@ extern "C" int gatmi_dense_attn_fwd_lists(int64_t B, int32_t N, int32_t H, int32
     a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed; a.seed_step = drop ? dropout_step_source() : nullptr; a.present = nullptr;
     const int cap = (int)((max_entries + 3) & ~(int64_t)3);
     a.lptr = lptr; a.lcol = lcol; a.lord = lord; a.lcap = cap;
-    return launch_graph_fwd8<true>(a, LPH, save, drop, graph8_fwd_lists_lds(N, H, cap), 0, reinterpret_cast<hipStream_t>(stream), "dense_attn_fwd_lists");
+    return launch_graph_fwd8_lists(a, LPH, save, drop, graph8_fwd_walk_lds(N, H), reinterpret_cast<hipStream_t>(stream), "dense_attn_fwd_lists");
 }
 
 extern "C" int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32_t dp,

@@ -35,10 +35,21 @@ def test_single_gpu_line_carries_the_contract():
 
 
 def test_multi_gpu_rehearsal_line_names_what_travelled():
-    d = _line("r02_rehearsal_gloo_2ranks_one_gpu.json")
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["backend"] == "gloo"
+    """The line of the driver's N > 1 command (rehearsed with two gloo ranks on one GPU): its value is the fastest
+    fully timed exchange-mode leg, every leg is reported, and configs[4]'s per-rank share is timed in the same run."""
+    d = _line("r03_rehearsal_gloo_2ranks_one_gpu.json")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["backend"] == "gloo" and d["config"]["name"] == "products"
     x = d["dist"]
-    assert x["halo"] == "exchange" and x["world_size"] == 2 and x["n_halo"] > 0
-    assert x["bytes_sent_per_step"] > 0 and x["a2a_ms"] > 0 and x["a2a_per_step"] >= 2
-    assert set(x["overlap_trial_ms"]) == {"on", "off"}
+    assert x["halo"] == "exchange" and x["world_size"] == 2 and x["n_halo"] > 0 and "exchange_error" not in x
+    assert x["bytes_sent_per_step"] > 0 and x["exchange_ms"] > 0 and x["exchanges_per_step"] >= 2
+    legs = x["legs"]
+    assert {"exchange_sequential", "exchange_pipeline", "replicate"} <= set(legs) and all("error" not in v for v in legs.values())
+    best = min(v["ms_per_step"] for k, v in legs.items() if k.startswith("exchange") and "trial" not in k)
+    assert abs(d["ms_per_step"] - best) < 1e-3 and x["overlap"] in ("off", "pipeline", "two_phase")
+    assert legs["exchange_sequential"]["bytes_sent_per_step"] == legs["exchange_pipeline"]["bytes_sent_per_step"]
     assert d["replicate_mode"]["bytes_sent_per_step"] == 0 and d["replicate_mode"]["value"] > 0
+    c4 = d["configs4"]
+    assert "12500000 nodes" in c4["workload"] and c4["world_size"] == 2 and "error" not in c4
+    assert c4["denominators_one_gpu"]["whole_graph_one_gpu_ms"] == 280.3 and c4["denominators_one_gpu"]["share_alone_ms"] == 36.1
+    assert c4["exchange"]["value"] > 0 and c4["replicate"]["value"] > 0 and c4["exchange"]["vs_whole_graph_on_one_gpu"] is None     # a ratio only at 8 ranks
+    assert all("error" not in v for v in c4["legs"].values())
