@@ -123,7 +123,7 @@ def main():
 
     def forward():
         _lib.call("gatmi_proj_fwd", ptr(x), n, F_IN, F_IN, ptr(W), ptr(a1), ptr(a2), ptr(b1), ptr(b2), H, D,
-                  ptr(Wh), None, 0, ptr(f1), ptr(f2), None, None, None, st)
+                  ptr(Wh), None, 0, ptr(f1), ptr(f2), None, None, None, 1.0, 0, st)
         _lib.call("gatmi_gat_fwd", n, H, D, ptr(g.items_csr), len(g.items_csr), ptr(g.split_csr) if len(g.split_csr) else None,
                   len(g.split_csr), ptr(g.col), ptr(Wh), _lib.DTYPE_F32, HD, ptr(f1), None, ptr(a2), ptr(b2), ptr(bias), None,
                   _lib.ACT_ELU, _lib.REDUCE_CONCAT, cfg.slope, 1.0, 1.0, 0, ptr(out), ptr(agg), ptr(pos), ptr(lse), ptr(q), ptr(ws_f), st)
@@ -135,7 +135,7 @@ def main():
                   len(g.split_csc), ptr(g.rowidx), ptr(g.perm), ptr(rec), _lib.DTYPE_F32, ldr, ptr(rec[:, HD:]), ldr, ptr(Wh), None, ptr(a2), ptr(b2),
                   ptr(df1), ptr(a1), ptr(a2), cfg.slope, 1.0, 1.0, 0, ptr(dWh), ptr(df2), ptr(ws_b), st)
         _lib.call("gatmi_proj_bwd_params", ptr(x), n, F_IN, F_IN, ptr(dWh), ptr(Wh), ptr(df1), ptr(df2), H, D,
-                  ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(ws_p), st)
+                  ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(ws_p), 1.0, 0, st)
 
     forward()
     torch.cuda.synchronize()

@@ -37,10 +37,10 @@ _SIGNATURES = {
     "gatmi_work_items_phased": (c_int, [c_int64, P, P, c_int32, P, P, P]),
     "gatmi_partition_rows": (c_int, [c_int64, c_int32, P, c_int32, P]),
     "gatmi_halo_plan": (c_int, [c_int32, c_int32, P, c_int64, P, P, P, P, P]),
-    "gatmi_proj_fwd": (c_int, [P, c_int64, c_int32, c_int64, P, P, P, P, P, c_int32, c_int32, P, P, c_int64, P, P, P, P, P, P]),
+    "gatmi_proj_fwd": (c_int, [P, c_int64, c_int32, c_int64, P, P, P, P, P, c_int32, c_int32, P, P, c_int64, P, P, P, P, P, c_float, c_uint64, P]),
     "gatmi_proj_bwd_ws_floats": (c_size_t, [c_int32, c_int32, c_int32]),
-    "gatmi_proj_bwd_params": (c_int, [P, c_int64, c_int32, c_int64, P, P, P, P, c_int32, c_int32, P, P, P, P, P, P, P]),
-    "gatmi_proj_bwd_input": (c_int, [P, c_int64, c_int32, P, c_int32, c_int32, P, c_int64, c_int, P]),
+    "gatmi_proj_bwd_params": (c_int, [P, c_int64, c_int32, c_int64, P, P, P, P, c_int32, c_int32, P, P, P, P, P, P, c_float, c_uint64, P]),
+    "gatmi_proj_bwd_input": (c_int, [P, c_int64, c_int32, P, c_int32, c_int32, P, c_int64, c_int, c_float, c_uint64, P]),
     "gatmi_proj_fwd_csr": (c_int, [P, P, P, c_int64, c_int32, P, P, P, P, P, c_int32, c_int32, P, P, P, P]),
     "gatmi_csr_row_normalize": (c_int, [c_int64, P, P, P, P]),
     "gatmi_proj_bwd_params_csr": (c_int, [P, P, P, c_int64, c_int32, P, P, P, P, c_int32, c_int32, P, P, P, P, P, P, P]),

@@ -147,9 +147,8 @@ __device__ __forceinline__ uint64_t feat_group_bits(uint64_t seed, uint64_t grou
 }
 __device__ __forceinline__ uint32_t feat_keep_threshold(float keep) { return (uint32_t)(keep * 65536.0f); }
 
-// feature-dropout of one float4 of row j (columns c0..c0+3, c0 and hd multiples of 4: one group)
-__device__ __forceinline__ float4 drop_feat(float4 v, uint64_t seed, int64_t j, int hd, int c0, float keep) {
-    const uint64_t z = feat_group_bits(seed, ((uint64_t)j * (uint64_t)hd + (uint64_t)c0) >> 2);
+// the four 16-bit fields of z against keep: kept elements scaled by 1/keep, the others zero
+__device__ __forceinline__ float4 drop_by_bits(float4 v, uint64_t z, float keep) {
     const uint32_t lo = (uint32_t)z, hi = (uint32_t)(z >> 32), thr = feat_keep_threshold(keep);
     const float inv = 1.0f / keep;
     v.x = (lo & 0xffffu) < thr ? v.x * inv : 0.f;
@@ -157,6 +156,20 @@ __device__ __forceinline__ float4 drop_feat(float4 v, uint64_t seed, int64_t j, 
     v.z = (hi & 0xffffu) < thr ? v.z * inv : 0.f;
     v.w = (hi >> 16) < thr ? v.w * inv : 0.f;
     return v;
+}
+
+// feature-dropout of one float4 of row j (columns c0..c0+3, c0 and hd multiples of 4: one group)
+__device__ __forceinline__ float4 drop_feat(float4 v, uint64_t seed, int64_t j, int hd, int c0, float keep) {
+    return drop_by_bits(v, feat_group_bits(seed, ((uint64_t)j * (uint64_t)hd + (uint64_t)c0) >> 2), keep);
+}
+
+// Dropout of the layer's INPUT (utils/layers.py:9) inside the projection kernels: the same 64 bits per group of
+// four elements, drawn under another salt; element (row, k) of the [n, F] input (F a multiple of 4) belongs to
+// group row * (F / 4) + k / 4 and takes field k & 3.  The forward projection masks the tile it loads, the weight
+// gradient masks the same tile again, and the input gradient is masked as it is stored: no dropped copy of X.
+constexpr uint64_t kInSeedSalt = 0x9FB21C651E98DF25ull;
+__device__ __forceinline__ float4 drop_in4(float4 v, uint64_t seed, int64_t row, int f4, int k4, float keep) {
+    return drop_by_bits(v, feat_group_bits(seed ^ kInSeedSalt, (uint64_t)row * (uint64_t)f4 + (uint64_t)k4), keep);
 }
 
 // one element of the same mask (row j, column c)

@@ -41,6 +41,12 @@ struct GemmArgs {
     const float *a1, *a2, *b1, *b2;
     float *f1, *f2;
     int H, LPH;
+    // dropout of the layer's input (utils/layers.py:9; device_common.h: drop_in4), 0 = off: a_keep masks A as it is
+    // loaded (A = X), c_keep masks C as it is stored (C = dX); rows of the masked matrix hold drop_f4 groups of four
+    float a_keep, c_keep;
+    int drop_f4;
+    uint64_t seed;
+    const uint64_t *seed_step;
 };
 
 // C[n, Nc] = A[n, K] . B[K, Nc]; B small.  VEC: A rows are 16-byte aligned and K % 4 == 0.
@@ -60,6 +66,7 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
     const int col0 = blockIdx.y * kTileCols;
     const int wrow = SPLITK ? 0 : wave * 32;           // first row of this wave inside the block
     const int wk = SPLITK ? wave * 32 : 0;             // first slab row of this wave
+    const uint64_t dseed = (g.a_keep != 0.f || g.c_keep != 0.f) ? seed_now(g) : 0;
 
     f32x4 acc[2][4];
 #pragma unroll
@@ -89,6 +96,7 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
                     if (VEC) {
                         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (rok[mt] && k < g.K) v = *reinterpret_cast<const float4 *>(g.A + arow[mt] * g.lda + k);
+                        if (g.a_keep != 0.f) v = drop_in4(v, dseed, arow[mt], g.drop_f4, k >> 2, g.a_keep);
                         a[s][mt][0] = v.x; a[s][mt][1] = v.y; a[s][mt][2] = v.z; a[s][mt][3] = v.w;
                     } else {
 #pragma unroll
@@ -141,6 +149,7 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
                     if (VEC) {
                         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (rok[mt] && k < g.K) v = *reinterpret_cast<const float4 *>(g.A + arow[mt] * g.lda + k);
+                        if (g.a_keep != 0.f) v = drop_in4(v, dseed, arow[mt], g.drop_f4, k >> 2, g.a_keep);
                         a[s][mt][0] = v.x; a[s][mt][1] = v.y; a[s][mt][2] = v.z; a[s][mt][3] = v.w;
                     } else {
     #pragma unroll
@@ -233,6 +242,7 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         float *cp = g.C + row * g.ldc + col;
         if (vec_store && col + 3 < g.Nc) {
+            if (g.c_keep != 0.f) v = drop_in4(v, dseed, row, g.drop_f4, col >> 2, g.c_keep);
             if (g.accumulate) {
                 const float4 o = *reinterpret_cast<const float4 *>(cp);
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(256) void tall_gemm_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------
 constexpr int kResWaves = 8;
 
-template <int NS, int NT>
+template <int NS, int NT, bool DROPIN>
 __global__ __launch_bounds__(64 * kResWaves) void proj_resident_kernel(GemmArgs g, int64_t n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ws = smem;                                   // [NS*16][kLdB]
@@ -287,6 +297,7 @@ __global__ __launch_bounds__(64 * kResWaves) void proj_resident_kernel(GemmArgs 
     }
     const int64_t tw = (int64_t)gridDim.x * kResWaves;
     int64_t tile = (int64_t)blockIdx.x * kResWaves + wave;
+    const uint64_t dseed = DROPIN ? seed_now(g) : 0;
 
     // The loads of the next tile are unconditional (rows past the end read the last row, k past K reads k = 0, and
     // the values are replaced by zeros when used): a load under a branch makes the compiler wait for ALL outstanding
@@ -311,7 +322,9 @@ __global__ __launch_bounds__(64 * kResWaves) void proj_resident_kernel(GemmArgs 
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const bool ok = rok && 16 * s + 4 * kq < g.K;
-            const float av[4] = {ok ? cur[s].x : 0.f, ok ? cur[s].y : 0.f, ok ? cur[s].z : 0.f, ok ? cur[s].w : 0.f};
+            float4 cs = cur[s];
+            if constexpr (DROPIN) cs = drop_in4(cs, dseed, tile * 16 + m, g.drop_f4, 4 * s + kq, g.a_keep);      // the tile is masked where it is used
+            const float av[4] = {ok ? cs.x : 0.f, ok ? cs.y : 0.f, ok ? cs.z : 0.f, ok ? cs.w : 0.f};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float *brow = Ws + (16 * s + 4 * kq + t) * kLdB + m;
@@ -521,9 +534,16 @@ __global__ __launch_bounds__(256) void xt_gemm_kernel(const float *X, int64_t n,
 // (column y0 + 4*col + c): a fixed permutation of the output, undone when the partial is parked.
 // Block (bx, by, bz): node chunks bx, bx+gridDim.x, ...; features [128*by, +64*FS); columns [64*bz, +64).
 // ------------------------------------------------------------------------------------------
-template <int FS>
+struct InDrop {
+    float keep;                  // 0 = off
+    int f4;
+    uint64_t seed;
+    const uint64_t *seed_step;
+};
+
+template <int FS, bool DROPIN>
 __global__ __launch_bounds__(256, FS == 1 ? 3 : 2) void xt_gemm_lines_kernel(const float *X, int64_t n, int F, int64_t ldx,
-                                                             const float *dY, int hd, float *ws) {
+                                                             const float *dY, int hd, float *ws, InDrop dr) {
     __shared__ float red[64 * FS * 65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;
@@ -541,6 +561,7 @@ __global__ __launch_bounds__(256, FS == 1 ? 3 : 2) void xt_gemm_lines_kernel(con
     for (int fs = 0; fs < FS; ++fs) fok[fs] = f0 + 64 * fs + 4 * m < F;      // F % 4 == 0: a float4 is all in or all out
     const bool yok = y0 + 4 * m < hd;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint64_t dseed = DROPIN ? seed_now(dr) : 0;
     // Every wave owns one contiguous run of rows (a multiple of four long) and walks it four rows a step.
     // Software pipeline: the rows of step t + 1 are requested before the matrix instructions of step t issue, so a
     // wave covers its own load latency.  The loads are unconditional (lanes past the run read its last row, lanes
@@ -574,7 +595,14 @@ __global__ __launch_bounds__(256, FS == 1 ? 3 : 2) void xt_gemm_lines_kernel(con
             const bool nok = r + 4 * d < rem;      // a group's later steps may lie past the run: they multiply zeros
             f32x4 xa[FS], yb;
 #pragma unroll
-            for (int fs = 0; fs < FS; ++fs) xa[fs] = (nok && fok[fs]) ? xq[d][fs] : zero;
+            for (int fs = 0; fs < FS; ++fs) {
+                xa[fs] = (nok && fok[fs]) ? xq[d][fs] : zero;
+                if constexpr (DROPIN) {                  // the forward projection's mask of this piece of X (utils/layers.py:9)
+                    const float4 t = drop_in4(make_float4(xa[fs][0], xa[fs][1], xa[fs][2], xa[fs][3]), dseed, start + r + 4 * d, dr.f4,
+                                              (f0 + 64 * fs + 4 * m) >> 2, dr.keep);
+                    xa[fs] = (f32x4){t.x, t.y, t.z, t.w};
+                }
+            }
             yb = (nok && yok) ? yq[d] : zero;
             load_step(r + 4 * (d + D), xq[d], yq[d]);          // past the end: the last row again, never used
 #pragma unroll
@@ -692,8 +720,11 @@ static int launch_resident(const GemmArgs &g, hipStream_t st, const char *name) 
     const int64_t n_tiles = (g.n + 15) / 16;
     const unsigned nb = (unsigned)std::min<int64_t>(512, (n_tiles + kResWaves - 1) / kResWaves);
     const size_t lds = (size_t)(NS * 16 + kResWaves * 16) * kLdB * sizeof(float);
-    if (g.Nc <= 16) hipLaunchKernelGGL((proj_resident_kernel<NS, 1>), dim3(nb), dim3(64 * kResWaves), lds, st, g, n_tiles);
-    else hipLaunchKernelGGL((proj_resident_kernel<NS, 4>), dim3(nb), dim3(64 * kResWaves), lds, st, g, n_tiles);
+    if (g.a_keep != 0.f) {
+        if (g.Nc <= 16) hipLaunchKernelGGL((proj_resident_kernel<NS, 1, true>), dim3(nb), dim3(64 * kResWaves), lds, st, g, n_tiles);
+        else hipLaunchKernelGGL((proj_resident_kernel<NS, 4, true>), dim3(nb), dim3(64 * kResWaves), lds, st, g, n_tiles);
+    } else if (g.Nc <= 16) hipLaunchKernelGGL((proj_resident_kernel<NS, 1, false>), dim3(nb), dim3(64 * kResWaves), lds, st, g, n_tiles);
+    else hipLaunchKernelGGL((proj_resident_kernel<NS, 4, false>), dim3(nb), dim3(64 * kResWaves), lds, st, g, n_tiles);
     GATMI_LAUNCH_CHECK(name);
     return GATMI_OK;
 }
@@ -701,7 +732,7 @@ static int launch_resident(const GemmArgs &g, hipStream_t st, const char *name) 
 static int launch_tall_gemm(const GemmArgs &g, hipStream_t st, const char *name) {
     if (g.n == 0 || g.Nc == 0) return GATMI_OK;
     const bool lines = (g.lda % 4 == 0) && (g.K % 4 == 0) && aligned16(g.A) && (g.ldc % 4 == 0) && aligned16(g.C);
-    if (lines && g.sbc == 1 && g.K <= 128 && g.Nc <= 64 && g.Nc % 4 == 0 && !g.accumulate && g.n >= 4096 &&
+    if (lines && g.sbc == 1 && g.K <= 128 && g.Nc <= 64 && g.Nc % 4 == 0 && !g.accumulate && g.n >= 4096 && g.c_keep == 0.f &&
         (!g.cbias || aligned16(g.cbias))) {
         switch ((g.K + 15) / 16) {
             case 1: return launch_resident<1>(g, st, name);
@@ -716,6 +747,9 @@ static int launch_tall_gemm(const GemmArgs &g, hipStream_t st, const char *name)
     }
     const unsigned gy = (unsigned)((g.Nc + kTileCols - 1) / kTileCols);
     const bool vec = (g.lda % 4 == 0) && (g.K % 4 == 0) && aligned16(g.A);
+    GATMI_REQUIRE(g.a_keep == 0.f || vec, GATMI_EUNSUPPORTED, "%s: input dropout inside the projection needs 16-byte aligned rows of a width that is a multiple of 4", name);
+    GATMI_REQUIRE(g.c_keep == 0.f || ((g.ldc & 3) == 0 && aligned16(g.C) && g.Nc % 4 == 0), GATMI_EUNSUPPORTED,
+                  "%s: input dropout on the input gradient needs 16-byte aligned rows of a width that is a multiple of 4", name);
     // few row blocks and a long K: split K over the waves of smaller blocks
     const bool splitk = g.K >= 256 && (g.n + kTileRows - 1) / kTileRows * gy < 512;
     if (splitk) {
@@ -755,13 +789,16 @@ static int launch_attn_param_grad(const float *Wh, const float *df1, const float
 }
 
 static int launch_xt_lines(const float *X, int64_t n, int F, int64_t ldx, const float *dY, int hd, float *ws,
-                           float *dW, hipStream_t st) {
+                           float *dW, const InDrop &dr, hipStream_t st) {
     const int FS = F <= 64 ? 1 : 2;
     const unsigned gy = (unsigned)((F + 64 * FS - 1) / (64 * FS)), gz = (unsigned)((hd + 63) / 64);
     const unsigned gx = (unsigned)std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 4 * kNodeChunk - 1) / (4 * kNodeChunk)));
     const dim3 grid(gx, gy, gz);
-    if (FS == 1) hipLaunchKernelGGL(xt_gemm_lines_kernel<1>, grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws);
-    else hipLaunchKernelGGL(xt_gemm_lines_kernel<2>, grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws);
+    if (dr.keep != 0.f) {
+        if (FS == 1) hipLaunchKernelGGL((xt_gemm_lines_kernel<1, true>), grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws, dr);
+        else hipLaunchKernelGGL((xt_gemm_lines_kernel<2, true>), grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws, dr);
+    } else if (FS == 1) hipLaunchKernelGGL((xt_gemm_lines_kernel<1, false>), grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws, dr);
+    else hipLaunchKernelGGL((xt_gemm_lines_kernel<2, false>), grid, dim3(256), 0, st, X, n, F, ldx, dY, hd, ws, dr);
     GATMI_LAUNCH_CHECK("xt_gemm_lines");
     hipLaunchKernelGGL(reduce_dw_kernel, dim3((F * hd + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, ws, (int)gx,
                        (int)(gy * 64 * FS), (int)(gz * 64), F, hd, hd, dW);
@@ -865,11 +902,14 @@ extern "C" int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t l
                               const float *W, const float *a1, const float *a2,
                               const float *b1, const float *b2, int32_t H, int32_t dp,
                               float *Wh, uint16_t *Wh16, int64_t ld16, float *f1, float *f2,
-                              const float *W_res, const float *b_res, float *res_out, void *stream) {
+                              const float *W_res, const float *b_res, float *res_out,
+                              float in_keep, uint64_t seed, void *stream) {
     int G, LPH;
     int rc = check_shape(H, dp, &G, &LPH);
     if (rc) return rc;
     GATMI_REQUIRE(n >= 0 && f_in > 0 && ldx >= f_in, GATMI_EINVAL, "proj_fwd: bad dims n=%lld f_in=%d ldx=%lld", (long long)n, f_in, (long long)ldx);
+    GATMI_REQUIRE(in_keep > 0.f && in_keep <= 1.f, GATMI_EINVAL, "proj_fwd: in_keep must be in (0,1]");
+    GATMI_REQUIRE(in_keep >= 1.f || f_in % 4 == 0, GATMI_EUNSUPPORTED, "proj_fwd: input dropout inside the projection needs f_in %% 4 == 0 (f_in = %d); mask the input outside", f_in);
     if (n == 0) return GATMI_OK;
     GATMI_REQUIRE(X && W && Wh, GATMI_EINVAL, "proj_fwd: null pointer");
     const bool logits = f1 || f2;
@@ -886,6 +926,7 @@ extern "C" int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t l
     g.A = X; g.n = n; g.K = f_in; g.lda = ldx;
     g.B = W; g.sbk = hd; g.sbc = 1; g.Nc = hd;
     g.C = Wh; g.ldc = hd; g.accumulate = 0; g.cbias = nullptr;
+    if (in_keep < 1.f) { g.a_keep = in_keep; g.drop_f4 = f_in / 4; g.seed = seed; g.seed_step = dropout_step_source(); }
     const bool fused = logits && hd <= kTileCols;
     if (fused) { g.a1 = a1; g.a2 = a2; g.b1 = b1; g.b2 = b2; g.f1 = f1; g.f2 = f2; g.H = H; g.LPH = LPH; }
     rc = launch_tall_gemm(g, st, "proj_fwd");
@@ -901,6 +942,7 @@ extern "C" int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t l
         r.A = X; r.n = n; r.K = f_in; r.lda = ldx;
         r.B = W_res; r.sbk = hd; r.sbc = 1; r.Nc = hd;
         r.C = res_out; r.ldc = hd; r.accumulate = 0; r.cbias = b_res;
+        r.a_keep = g.a_keep; r.drop_f4 = g.drop_f4; r.seed = g.seed; r.seed_step = g.seed_step;      // the residual branch reads the same dropped input (utils/layers.py:30)
         rc = launch_tall_gemm(r, st, "proj_fwd residual");
         if (rc) return rc;
     }
@@ -924,11 +966,12 @@ extern "C" int gatmi_proj_bwd_params(const float *X, int64_t n, int32_t f_in, in
                                      const float *dWh, const float *Wh, const float *df1, const float *df2,
                                      int32_t H, int32_t dp,
                                      float *dW, float *da1, float *da2, float *db1, float *db2,
-                                     float *ws, void *stream) {
+                                     float *ws, float in_keep, uint64_t seed, void *stream) {
     int G, LPH;
     int rc = check_shape(H, dp, &G, &LPH);
     if (rc) return rc;
     GATMI_REQUIRE(n >= 0 && f_in > 0 && ldx >= f_in, GATMI_EINVAL, "proj_bwd_params: bad dims");
+    GATMI_REQUIRE(in_keep > 0.f && in_keep <= 1.f, GATMI_EINVAL, "proj_bwd_params: in_keep must be in (0,1]");
     GATMI_REQUIRE(X && dWh && dW && ws, GATMI_EINVAL, "proj_bwd_params: null pointer");
     GATMI_REQUIRE(!Wh || (df1 && df2 && da1 && da2 && db1 && db2), GATMI_EINVAL, "proj_bwd_params: Wh needs df1, df2, da1, da2, db1, db2");
     GATMI_REQUIRE_ALIGNED(Wh); GATMI_REQUIRE_ALIGNED(ws);
@@ -941,8 +984,11 @@ extern "C" int gatmi_proj_bwd_params(const float *X, int64_t n, int32_t f_in, in
         if (rc) return rc;
     }
     // (the kernel forms row offsets as 32-bit row x 32-bit row stride in bytes)
+    InDrop dr{};
+    if (in_keep < 1.f) { dr.keep = in_keep; dr.f4 = f_in / 4; dr.seed = seed; dr.seed_step = dropout_step_source(); }
     if (ldx % 4 == 0 && f_in % 4 == 0 && aligned16(X) && aligned16(dWh) && f_in <= 1024 && ldx < ((int64_t)1 << 29))
-        return launch_xt_lines(X, n, f_in, ldx, dWh, hd, ws, dW, st);
+        return launch_xt_lines(X, n, f_in, ldx, dWh, hd, ws, dW, dr, st);
+    GATMI_REQUIRE(in_keep >= 1.f, GATMI_EUNSUPPORTED, "proj_bwd_params: input dropout inside the projection needs 16-byte aligned rows of X and dWh and f_in %% 4 == 0, f_in <= 1024 (f_in = %d); mask the input outside", f_in);
     // rows of X that are not 16-byte aligned: dW in column slabs of 64 (one slab for hd <= 64); the
     // slabs share the workspace, which the stream order makes safe
     for (int c0 = 0; c0 < hd; c0 += 64) {
@@ -960,11 +1006,13 @@ extern "C" int gatmi_proj_bwd_params(const float *X, int64_t n, int32_t f_in, in
 
 extern "C" int gatmi_proj_bwd_input(const float *dWh, int64_t n, int32_t f_in, const float *W,
                                     int32_t H, int32_t dp, float *dX, int64_t lddx, int accumulate,
-                                    void *stream) {
+                                    float in_keep, uint64_t seed, void *stream) {
     int G, LPH;
     int rc = check_shape(H, dp, &G, &LPH);
     if (rc) return rc;
     GATMI_REQUIRE(n >= 0 && f_in > 0 && lddx >= f_in, GATMI_EINVAL, "proj_bwd_input: bad dims");
+    GATMI_REQUIRE(in_keep > 0.f && in_keep <= 1.f, GATMI_EINVAL, "proj_bwd_input: in_keep must be in (0,1]");
+    GATMI_REQUIRE(in_keep >= 1.f || f_in % 4 == 0, GATMI_EUNSUPPORTED, "proj_bwd_input: input dropout inside the projection needs f_in %% 4 == 0 (f_in = %d)", f_in);
     if (n == 0) return GATMI_OK;
     GATMI_REQUIRE(dWh && W && dX, GATMI_EINVAL, "proj_bwd_input: null pointer");
     GATMI_REQUIRE_ALIGNED(dWh);
@@ -973,6 +1021,7 @@ extern "C" int gatmi_proj_bwd_input(const float *dWh, int64_t n, int32_t f_in, c
     g.A = dWh; g.n = n; g.K = hd; g.lda = hd;
     g.B = W; g.sbk = 1; g.sbc = hd; g.Nc = f_in;   // B[k=c_hd][c=f] = W[f][c_hd]
     g.C = dX; g.ldc = lddx; g.accumulate = accumulate; g.cbias = nullptr;
+    if (in_keep < 1.f) { g.c_keep = in_keep; g.drop_f4 = f_in / 4; g.seed = seed; g.seed_step = dropout_step_source(); }
     return launch_tall_gemm(g, reinterpret_cast<hipStream_t>(stream), "proj_bwd_input");
 }
 

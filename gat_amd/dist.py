@@ -543,7 +543,7 @@ class DistSparseGATLayerFn(torch.autograd.Function):
             ldf = ops._bf16_record_elems(H, dp)
             gtab, gdt = torch.empty((n_src, ldf), dtype=torch.bfloat16, device=x.device), _lib.DTYPE_BF16
         _lib.call("gatmi_proj_fwd", ptr(x), n_proj, F, x.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1.contiguous()),
-                  ptr(b2c), H, dp, ptr(feat), ptr(gtab) if bf16 else None, ldf, ptr(f1), ptr(f2), None, None, None, st)
+                  ptr(b2c), H, dp, ptr(feat), ptr(gtab) if bf16 else None, ldf, ptr(f1), ptr(f2), None, None, None, 1.0, 0, st)
         ticket = pend_fwd = None
         if not replicate and ex.world > 1:
             # fp32: only the Wh rows travel, the receiving sweep forms <Wh_j, a2> + b2 from them; bf16 rows

@@ -170,25 +170,29 @@ class GATHeads(nn.Module):
             graph_or_bias = g                                                # same surface, the mask's lists instead of its floats
         elif g is not None and seq.dim() == 3:
             return self.forward(seq, g, act, reduce, in_drop, coef_drop, training, seed)
-        if training and in_drop > 0.0:
-            seq = torch.nn.functional.dropout(seq, in_drop, True)            # layers.py:8-9
+        x_drop = 0.0
+        if training and in_drop > 0.0:                                       # layers.py:8-9
+            if ops.input_dropout_fusable(seq.reshape(-1, seq.shape[-1])):
+                x_drop = in_drop                                             # the projection kernels mask the tiles of X they load
+            else:
+                seq = torch.nn.functional.dropout(seq, in_drop, True)
         if seed is None and training and (in_drop > 0.0 or coef_drop > 0.0):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         groups = _head_groups(H, D)
         if len(groups) == 1:
-            return self._run(seq, graph_or_bias, slice(0, H), act, reduce, in_drop, coef_drop, training, seed)
+            return self._run(seq, graph_or_bias, slice(0, H), act, reduce, in_drop, coef_drop, training, seed, x_drop)
         # head counts the fused kernels do not take in one sweep (not a power of two, or too wide):
         # power-of-two groups of heads, concatenated (and averaged afterwards if asked to)
         if act != "identity" and reduce == "mean":
             raise ValueError("mean over heads is defined for the identity activation (models/sp_gat.py:30-32)")
         outs = [self._run(seq, graph_or_bias, slice(h0, h0 + hn), act, "concat", in_drop, coef_drop, training,
-                          None if seed is None else seed + h0) for h0, hn in groups]
+                          None if seed is None else seed + h0, x_drop) for h0, hn in groups]
         out = torch.cat(outs, dim=-1)
         if reduce == "mean":
             out = out.reshape(*out.shape[:-1], H, D).mean(-2)
         return out
 
-    def _run(self, seq, graph_or_bias, hs, act, reduce, in_drop, coef_drop, training, seed):
+    def _run(self, seq, graph_or_bias, hs, act, reduce, in_drop, coef_drop, training, seed, x_drop=0.0):
         """One fused sweep over the heads in slice hs."""
         hn, D = hs.stop - hs.start, self.width
         sl = lambda t: t[hs] if hn != self.heads else t
@@ -196,10 +200,10 @@ class GATHeads(nn.Module):
         wr = (self.W_res[:, hs] if hn != self.heads else self.W_res) if self.has_res else None
         br = sl(self.b_res) if self.has_res else None
         if isinstance(graph_or_bias, CSRGraph):
-            cfg = ops.make_cfg(hn, D, act, reduce, coef_drop, in_drop, training, seed, storage=self.storage)
+            cfg = ops.make_cfg(hn, D, act, reduce, coef_drop, in_drop, training, seed, storage=self.storage, x_drop=x_drop)
             return ops.sparse_gat_layer(seq, W, sl(self.a1), sl(self.a2), sl(self.b1), sl(self.b2), sl(self.bias),
                                         graph_or_bias, cfg, wr, br)
-        cfg = ops.make_cfg(hn, D, act, "concat", coef_drop, in_drop, training, seed)
+        cfg = ops.make_cfg(hn, D, act, "concat", coef_drop, in_drop, training, seed, x_drop=x_drop)
         out = ops.dense_gat_layer(seq, W, sl(self.a1), sl(self.a2), sl(self.b1), sl(self.b2), sl(self.bias),
                                   graph_or_bias, cfg, wr, br)
         if reduce == "mean":

@@ -51,7 +51,7 @@ def _f32(t):
 
 
 class _Cfg:
-    __slots__ = ("H", "D", "dp", "activation", "reduce", "slope", "coef_keep", "feat_keep", "seed", "storage", "mask_path")
+    __slots__ = ("H", "D", "dp", "activation", "reduce", "slope", "coef_keep", "feat_keep", "x_keep", "seed", "storage", "mask_path")
 
 
 def _bf16_record_elems(H, dp):
@@ -73,10 +73,19 @@ def _new(shape, like, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
+def input_dropout_fusable(x2d):
+    """Whether the projection kernels can apply the dropout of the layer's input (utils/layers.py:9) to the tiles
+    of X they load (cfg.x_keep), instead of a separate pass that writes a dropped copy: dense rows that are 16-byte
+    aligned and a multiple of four wide (and not wider than the whole-line weight-gradient kernel takes)."""
+    return (torch.is_tensor(x2d) and x2d.dim() == 2 and x2d.shape[1] % 4 == 0 and x2d.shape[1] <= 1024 and x2d.stride(1) == 1
+            and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0)
+
+
 def _project(x2d, W, a1, a2, b1, b2, cfg, W_res=None, b_res=None, Wh16_out=None):
     """K1: Wh = X.W (+ f1, f2) on [n, F] rows (dense tensor or SparseFeatures).  Returns padded
     parameter views and outputs.  Wh16_out: a list that receives the bf16 gather table of the forward kernel,
-    one record [hd bf16 of Wh | the row's fp32 f2 | pad] per row, written by the projection's epilogue."""
+    one record [hd bf16 of Wh | the row's fp32 f2 | pad] per row, written by the projection's epilogue.
+    cfg.x_keep < 1: the input is dropped inside the kernels (see input_dropout_fusable)."""
     n, F = x2d.shape
     sparse_x = isinstance(x2d, SparseFeatures)
     if sparse_x and W_res is not None:
@@ -102,13 +111,15 @@ def _project(x2d, W, a1, a2, b1, b2, cfg, W_res=None, b_res=None, Wh16_out=None)
         Wh16 = torch.empty((n, ld16), dtype=torch.bfloat16, device=Wh.device)
         Wh16_out.append(Wh16)
     if sparse_x:
+        if cfg.x_keep < 1.0:
+            raise ValueError("sparse node features: drop the stored values outside (SparseFeatures.dropout)")
         _lib.call("gatmi_proj_fwd_csr", ptr(x2d.rowptr), ptr(x2d.col), ptr(x2d.val), n, F, ptr(Wp), ptr(a1p), ptr(a2p),
                   ptr(b1c), ptr(b2c), H, dp, ptr(Wh), ptr(f1), ptr(f2), _lib.current_stream())
         if Wh16 is not None:
             _lib.call("gatmi_to_bf16_records", ptr(Wh), ptr(f2), n, H, dp, ld16, ptr(Wh16), _lib.current_stream())
         return Wp, a1p, a2p, None, Wh, f1, f2, None
     _lib.call("gatmi_proj_fwd", ptr(x2d), n, F, x2d.stride(0), ptr(Wp), ptr(a1p), ptr(a2p), ptr(b1c), ptr(b2c),
-              H, dp, ptr(Wh), ptr(Wh16), ld16, ptr(f1), ptr(f2), ptr(Wrp), ptr(brp), ptr(res), _lib.current_stream())
+              H, dp, ptr(Wh), ptr(Wh16), ld16, ptr(f1), ptr(f2), ptr(Wrp), ptr(brp), ptr(res), cfg.x_keep, cfg.seed, _lib.current_stream())
     return Wp, a1p, a2p, Wrp, Wh, f1, f2, res
 
 
@@ -129,19 +140,20 @@ def _project_backward(x2d, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, need_dx):
         _lib.call("gatmi_proj_bwd_params_csr", ptr(x2d.t_rowptr), ptr(x2d.t_row), ptr(x2d.t_val), n, F, ptr(dWh), ptr(Wh),
                   ptr(df1), ptr(df2), H, dp, ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(ws), st)
         return None, unpad(dW, (F,)), unpad(da1, ()), unpad(da2, ()), db1, db2, None
+    xk, sd = cfg.x_keep, cfg.seed
     _lib.call("gatmi_proj_bwd_params", ptr(x2d), n, F, x2d.stride(0), ptr(dWh), ptr(Wh), ptr(df1), ptr(df2), H, dp,
-              ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(ws), st)
+              ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(ws), xk, sd, st)
     dWr = None
     if Wrp is not None:
         dWr = _new((F, hd), x2d)
         _lib.call("gatmi_proj_bwd_params", ptr(x2d), n, F, x2d.stride(0), ptr(g), None, None, None, H, dp,
-                  ptr(dWr), None, None, None, None, ptr(ws), st)
+                  ptr(dWr), None, None, None, None, ptr(ws), xk, sd, st)
     dx = None
     if need_dx:
         dx = _new((n, F), x2d)
-        _lib.call("gatmi_proj_bwd_input", ptr(dWh), n, F, ptr(Wp), H, dp, ptr(dx), F, 0, st)
+        _lib.call("gatmi_proj_bwd_input", ptr(dWh), n, F, ptr(Wp), H, dp, ptr(dx), F, 0, xk, sd, st)
         if Wrp is not None:
-            _lib.call("gatmi_proj_bwd_input", ptr(g), n, F, ptr(Wrp), H, dp, ptr(dx), F, 1, st)
+            _lib.call("gatmi_proj_bwd_input", ptr(g), n, F, ptr(Wrp), H, dp, ptr(dx), F, 1, xk, sd, st)
     return (dx, unpad(dW, (F,)), unpad(da1, ()), unpad(da2, ()), db1, db2,
             None if dWr is None else unpad(dWr, (F,)))
 
@@ -431,10 +443,12 @@ class DenseGATLayerFn(torch.autograd.Function):
 
 
 def make_cfg(H, D, activation="elu", reduce="concat", coef_drop=0.0, in_drop=0.0, training=False, seed=None,
-             slope=LEAKY_SLOPE, storage="f32", mask_path="auto"):
+             slope=LEAKY_SLOPE, storage="f32", mask_path="auto", x_drop=0.0):
     """Static description of one layer call.  coef_drop / in_drop are the reference's dropout
     rates (utils/layers.py:20,22); they act only when training is true, and rate 0 is an exact
-    identity (no mask is drawn).  storage="bf16" keeps the two gathered tables of the CSR path (Wh
+    identity (no mask is drawn).  x_drop: the same in_drop rate applied to the layer's INPUT (utils/layers.py:9)
+    inside the projection kernels, for inputs that allow it (input_dropout_fusable; the caller then does not drop
+    the input itself).  storage="bf16" keeps the two gathered tables of the CSR path (Wh
     rows in the forward sweep, g rows in the backward sweep) in bf16 — half the gather traffic,
     fp32 arithmetic, results within the 2e-2 class instead of 1e-5.  mask_path (dense [B,N,N] masks
     only): "auto" picks the compacted-list kernels for sparse masks and the matrix-core kernels for
@@ -449,8 +463,9 @@ def make_cfg(H, D, activation="elu", reduce="concat", coef_drop=0.0, in_drop=0.0
     c.activation, c.reduce, c.slope = activation, reduce, float(slope)
     c.coef_keep = 1.0 - float(coef_drop) if training else 1.0
     c.feat_keep = 1.0 - float(in_drop) if training else 1.0
+    c.x_keep = 1.0 - float(x_drop) if training else 1.0
     if seed is None:
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (c.coef_keep < 1.0 or c.feat_keep < 1.0) else 0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (c.coef_keep < 1.0 or c.feat_keep < 1.0 or c.x_keep < 1.0) else 0
     c.seed = int(seed)
     if storage not in ("f32", "bf16"):
         raise ValueError("storage must be 'f32' or 'bf16'")
@@ -594,8 +609,8 @@ class BnfAggregateFn(torch.autograd.Function):
         da1, da2 = _new((hd,), xp), _new((hd,), xp)
         db1, db2 = _new((H,), xp), _new((H,), xp)
         _lib.call("gatmi_proj_bwd_params", ptr(xp), n, fp, fp, ptr(dZ), ptr(Z), ptr(df1), ptr(df2), H, cfg.dp,
-                  ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(wsp), st)
-        _lib.call("gatmi_proj_bwd_input", ptr(dZ), n, fp, ptr(Wp), H, cfg.dp, ptr(dx), fp, 1, st)
+                  ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(wsp), 1.0, 0, st)
+        _lib.call("gatmi_proj_bwd_input", ptr(dZ), n, fp, ptr(Wp), H, cfg.dp, ptr(dx), fp, 1, 1.0, 0, st)
         unp = lambda t, lead: t.reshape(*lead, H, cfg.dp)[..., :Dz]
         return (dx[:, :F].reshape(B, N, F), dA, unp(dW, (fp,))[:F], unp(da1, ()), unp(da2, ()), db1, db2,
                 dm[:H], dm[H:], None)

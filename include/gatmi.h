@@ -134,28 +134,36 @@ int gatmi_halo_plan(int32_t nparts, int32_t rank, const int64_t *part, int64_t n
  *   from the same registers: one record per row, ld16 bf16 elements apart (ld16 >= hd + 2H, a multiple of 8),
  *   [hd bf16 values of Wh, round to nearest even | the row's H fp32 f2 values | padding, left untouched].
  *   W_res/b_res/res_out: optional second projection of the same X (residual branch, utils/layers.py:30),
- *   NULL to skip. */
+ *   NULL to skip.
+ *   in_keep < 1: dropout of the layer's input (utils/layers.py:8-9, keep probability in_keep) applied to the
+ *   tile of X as it is loaded — X' = X * mask / in_keep is never written.  The mask is a counter hash of
+ *   (seed, row, column / 4), 16 bits per element; gatmi_proj_bwd_params and gatmi_proj_bwd_input called with
+ *   the same in_keep and seed redraw it.  Needs f_in % 4 == 0 and 16-byte aligned rows of X
+ *   (GATMI_EUNSUPPORTED otherwise: mask the input outside); in_keep = 1: no mask, any shape. */
 int gatmi_proj_fwd(const float *X, int64_t n, int32_t f_in, int64_t ldx,
                    const float *W, const float *a1, const float *a2,
                    const float *b1, const float *b2, int32_t H, int32_t dp,
                    float *Wh, uint16_t *Wh16, int64_t ld16, float *f1, float *f2,
-                   const float *W_res, const float *b_res, float *res_out, void *stream);
+                   const float *W_res, const float *b_res, float *res_out,
+                   float in_keep, uint64_t seed, void *stream);
 
 /* Parameter gradients of the projection: dW = X^T . dWh [f_in, hd]; and, when Wh != NULL,
  * da1 = sum_i df1[i,h] * Wh[i,h,:], da2 likewise with df2, db1 = sum_i df1, db2 = sum_i df2
- * (the backward of layers.py:11,14,15).  ws: gatmi_proj_bwd_ws_floats(f_in, H, dp) floats. */
+ * (the backward of layers.py:11,14,15).  ws: gatmi_proj_bwd_ws_floats(f_in, H, dp) floats.
+ * in_keep, seed: as passed to gatmi_proj_fwd (X stands for the dropped input X' of that call). */
 size_t gatmi_proj_bwd_ws_floats(int32_t f_in, int32_t H, int32_t dp);
 int gatmi_proj_bwd_params(const float *X, int64_t n, int32_t f_in, int64_t ldx,
                           const float *dWh, const float *Wh, const float *df1, const float *df2,
                           int32_t H, int32_t dp,
                           float *dW, float *da1, float *da2, float *db1, float *db2,
-                          float *ws, void *stream);
+                          float *ws, float in_keep, uint64_t seed, void *stream);
 
 /* Input gradient of the projection: dX [n, f_in] (row stride lddx) = dWh . W^T
- * (+= when accumulate != 0). */
+ * (+= when accumulate != 0).  in_keep < 1 (with the seed of gatmi_proj_fwd): the gradient with respect to the
+ * UNdropped input, i.e. the product times mask / in_keep, applied as the rows are stored. */
 int gatmi_proj_bwd_input(const float *dWh, int64_t n, int32_t f_in, const float *W,
                          int32_t H, int32_t dp, float *dX, int64_t lddx, int accumulate,
-                         void *stream);
+                         float in_keep, uint64_t seed, void *stream);
 
 /* The projection for SPARSE node features: X [n, f_in] in CSR (xrowptr [n+1], xcol, xval in DEVICE
  * memory), as the sparse tuple of preprocess_features (utils/process.py:155-162, the second return

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import ref_numpy, ref_torch
-from tests.util import assert_close, feat_keep_host, keep_mask_host, layer_params, random_graph
+from tests.util import assert_close, feat_keep_host, input_keep_host, keep_mask_host, layer_params, random_graph
 
 pytestmark = pytest.mark.gpu
 
@@ -77,6 +77,73 @@ def test_rate_zero_and_eval_are_exact_identities():
     assert not torch.equal(base, dropped)
     assert torch.equal(dropped, run(ops.make_cfg(H, D, "elu", coef_drop=0.6, in_drop=0.6, training=True, seed=5)))
     assert not torch.equal(dropped, run(ops.make_cfg(H, D, "elu", coef_drop=0.6, in_drop=0.6, training=True, seed=6)))
+
+
+@pytest.mark.parametrize("n,F,H,D,res,x_drop", [(300, 16, 8, 8, False, 0.6), (5000, 100, 8, 8, False, 0.6), (4500, 64, 1, 7, False, 0.3),
+                                                 (700, 512, 4, 16, True, 0.5), (4200, 36, 2, 8, True, 0.6)])
+def test_input_dropout_inside_the_projection_replays(n, F, H, D, res, x_drop):
+    """Dropout of the layer's input (utils/layers.py:9) applied by the projection kernels to the tiles of X they
+    load — every projection kernel family: the whole-row kernel with resident weights (n >= 4096, F <= 128), the
+    slab kernel, its split-K form (F >= 256), the residual projection, the whole-line weight gradient and the
+    masked store of the input gradient.  The host twin of the hash gives the mask; the oracle is fed X * mask / keep."""
+    from gat_amd import CSRGraph, ops
+    dev = torch.device("cuda:0")
+    dst, src = random_graph(n, 4.0, seed=F, hubs=1, hub_deg=100)
+    rowptr, col = ref_numpy.coo_to_csr(np.stack([dst, src], 1), n)
+    p = layer_params(F, H, D, seed=13, res=res)
+    x = np.random.default_rng(14).normal(0, 1, (n, F))
+    seed = 24681357
+    tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+    xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
+    assert ops.input_dropout_fusable(xt)
+    cfg = ops.make_cfg(H, D, "elu", "concat", training=True, seed=seed, x_drop=x_drop)
+    graph = CSRGraph.from_coo(dst, src, n, dev)
+    out = ops.sparse_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], graph, cfg,
+                               tp.get("W_res"), tp.get("b_res"))
+    dout = np.random.default_rng(15).normal(0, 1, tuple(out.shape))
+    out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
+    keep = 1.0 - x_drop
+    xm = input_keep_host(seed, n, F, keep)
+    assert abs(xm.mean() - keep) < 0.02
+    rp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = ref_torch.layer_csr(rx * torch.tensor(xm.astype(np.float64)) / keep, rp, torch.tensor(rowptr), torch.tensor(col), "elu", "concat", residual=res)
+    ref.backward(torch.tensor(dout))
+    assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), what="forward with input dropout")
+    got_dx = xt.grad.cpu().numpy()
+    assert np.all(got_dx[~xm] == 0.0)
+    assert_close(got_dx, rx.grad.numpy(), atol_scale=5e-6, what="dX")
+    for k in p:
+        if k in ("b1", "b2"):
+            continue
+        assert_close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), atol_scale=5e-6, what="d" + k)
+    # rate 0 draws no mask: bit-identical to the layer without the option
+    base = ops.sparse_gat_layer(xt.detach(), tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], graph, ops.make_cfg(H, D, "elu", "concat"),
+                                tp.get("W_res"), tp.get("b_res"))
+    zero = ops.sparse_gat_layer(xt.detach(), tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], graph,
+                                ops.make_cfg(H, D, "elu", "concat", training=True, seed=seed, x_drop=0.0), tp.get("W_res"), tp.get("b_res"))
+    assert torch.equal(base, zero)
+
+
+def test_heads_module_drops_its_input_inside_the_projection_when_it_can():
+    """GATHeads with in_drop > 0: an aligned input takes the fused mask (no dropped copy of X), an input whose width
+    is not a multiple of four falls back to a separate dropout pass; both train (finite gradients, masks change with the seed)."""
+    from gat_amd import CSRGraph, layers
+    dev = torch.device("cuda:0")
+    n = 500
+    dst, src = random_graph(n, 4.0, seed=2)
+    graph = CSRGraph.from_coo(dst, src, n, dev)
+    for F in (24, 23):
+        m = layers.GATHeads(F, 8, 8, device=dev)
+        x = torch.randn(n, F, device=dev, generator=torch.Generator(device=dev).manual_seed(F), requires_grad=True)
+        a = m(x, graph, "elu", "concat", in_drop=0.5, coef_drop=0.0, training=True, seed=7)
+        b = m(x, graph, "elu", "concat", in_drop=0.5, coef_drop=0.0, training=True, seed=7)
+        c = m(x, graph, "elu", "concat", in_drop=0.5, coef_drop=0.0, training=True, seed=8)
+        if F % 4 == 0:
+            assert torch.equal(a, b)                       # in-kernel masks are a function of the seed
+        assert not torch.equal(a, c)
+        a.sum().backward()
+        assert torch.isfinite(x.grad).all() and float((x.grad == 0).float().mean()) > 0.3
 
 
 @pytest.mark.parametrize("path", ["dense", "lists"])

@@ -71,7 +71,7 @@ def test_graph_without_edges_and_zero_sizes():
     assert torch.equal(xt.grad, torch.zeros_like(xt.grad))
     # zero rows through the C ABI: accepted, nothing launched
     st = _lib.current_stream()
-    _lib.call("gatmi_proj_fwd", None, 0, 5, 5, None, None, None, None, None, 2, 4, None, None, 0, None, None, None, None, None, st)
+    _lib.call("gatmi_proj_fwd", None, 0, 5, 5, None, None, None, None, None, 2, 4, None, None, 0, None, None, None, None, None, 1.0, 0, st)
     _lib.call("gatmi_gat_fwd", 0, 2, 4, None, 0, None, 0, None, None, 0, 8, None, None, None, None, None, None, 1, 0,
               0.2, 1.0, 1.0, 0, None, None, None, None, None, None, st)
     _lib.call("gatmi_dense_attn_fwd", 0, 16, 8, 8, None, None, None, None, None, None, 1, 0.2, 1.0, 1.0, 0,
@@ -124,7 +124,7 @@ def test_c_abi_rejects_what_it_is_not_built_for():
         ("gatmi_dense_attn_fwd_masked", (1, 4, 1, 8, t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), None, None, 1, 0.2,
                                          1.0, 1.0, 0, t.data_ptr(), None, None, None, None, None, st), "narrow"),
         ("gatmi_proj_fwd", (t.data_ptr() + 4, 4, 4, 4, t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 2, 4,
-                            t.data_ptr() + 4, None, 0, t.data_ptr(), t.data_ptr(), None, None, None, st), "aligned"),
+                            t.data_ptr() + 4, None, 0, t.data_ptr(), t.data_ptr(), None, None, None, 1.0, 0, st), "aligned"),
     ]
     for name, args, needle in cases:
         with pytest.raises(_lib.GatmiError) as e:

@@ -61,7 +61,7 @@ def test_ctypes_only_sp_attn_head():
     wh, f1, f2, out = alloc(n * dp), alloc(n), alloc(n), alloc(n * dp)
     ptr = lambda t: p(t.data_ptr())
     ok(g.gatmi_proj_fwd(upload(x), i64(n), f_in, i64(f_in), dp_["W"], dp_["a1"], dp_["a2"], dp_["b1"], dp_["b2"], H, dp,
-                        ptr(wh), None, i64(0), ptr(f1), ptr(f2), None, None, None, stream), "proj_fwd")
+                        ptr(wh), None, i64(0), ptr(f1), ptr(f2), None, None, None, ctypes.c_float(1.0), ctypes.c_uint64(0), stream), "proj_fwd")
     ws = alloc(g.gatmi_gat_fwd_ws_floats(i64(nl.value), H, dp))
     ok(g.gatmi_gat_fwd(i64(n), H, dp, upload(items), i64(ni.value), upload(split[:ns.value]), i64(ns.value), upload(col[:nnz.value]),
                        ptr(wh), 0, i64(dp), ptr(f1),       # fp32 rows, dp floats apart

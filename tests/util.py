@@ -105,11 +105,11 @@ def _mix32(x):
         return x ^ (x >> np.uint64(16))
 
 
-def feat_keep_host(seed, elem, keep):
+def feat_keep_host(seed, elem, keep, salt=0):
     """Host twin of drop_feat / drop_feat1 in gat_amd/csrc/device_common.h: element index e of the [rows, hd]
     table belongs to group e >> 2, 64 mixed bits per group, 16 bits per element against keep * 65536."""
     elem = np.asarray(elem).astype(np.uint64)
-    s = (scramble_seed(seed) ^ FEAT_SALT) & _M64
+    s = (scramble_seed(seed) ^ salt ^ FEAT_SALT) & _M64
     m32 = np.uint64(0xFFFFFFFF)
     group = elem >> np.uint64(2)
     with np.errstate(over="ignore"):
@@ -118,6 +118,19 @@ def feat_keep_host(seed, elem, keep):
     z = (hi << np.uint64(32)) | lo
     field = (z >> (np.uint64(16) * (elem & np.uint64(3)))) & np.uint64(0xffff)
     return field < np.uint64(int(np.float32(keep) * np.float32(65536.0)))
+
+
+IN_SALT = 0x9FB21C651E98DF25
+
+
+def input_keep_host(seed, n, F, keep):
+    """Host twin of drop_in4 in gat_amd/csrc/device_common.h (dropout of the layer's input inside the projection
+    kernels): element (row, k) belongs to group row * (F / 4) + k / 4, field k & 3 -> bool [n, F]."""
+    assert F % 4 == 0
+    rows = np.arange(n, dtype=np.uint64)[:, None]
+    k = np.arange(F, dtype=np.uint64)[None, :]
+    elem = (rows * np.uint64(F // 4) + (k >> np.uint64(2))) * np.uint64(4) + (k & np.uint64(3))
+    return feat_keep_host(seed, elem, keep, salt=IN_SALT)
 
 
 def sparse_dropout_masks(seed, n_entries, n, H, D, dp, coef_drop, in_drop):
