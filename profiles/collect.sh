@@ -39,13 +39,24 @@ for part in $PARTS; do
         pmc tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -- $S || exit 1
         pmc sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- $S || exit 1 ;;
     stats_dense)
-        for mp in lists dense csr; do
+        for mp in lists dense csr prebuilt; do
             echo "[collect] kernel stats, bench_dense --mask-path $mp"
             rm -rf "$OUT/stats_dense_$mp"
             timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_dense_$mp" --output-format csv -- python3 "$ROOT/benchmarks/bench_dense.py" --mask-path $mp > "$OUT/stats_dense_$mp.log" 2>&1 || exit 1
-        done ;;
+        done
+        for mp in lists prebuilt; do          # the reference's training rates (execute_cora.py:107)
+            echo "[collect] kernel stats, bench_dense --mask-path $mp --dropout 0.6"
+            rm -rf "$OUT/stats_dense_${mp}_drop"
+            timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_dense_${mp}_drop" --output-format csv -- python3 "$ROOT/benchmarks/bench_dense.py" --mask-path $mp --dropout 0.6 > "$OUT/stats_dense_${mp}_drop.log" 2>&1 || exit 1
+        done
+        : > "$OUT/bench_dense.jsonl"
+        for args in "--mask-path lists" "--mask-path prebuilt" "--mask-path lists --dropout 0.6" "--mask-path prebuilt --dropout 0.6" "--mask-path dense" "--mask-path csr"; do
+            timeout -k 10 200 python3 "$ROOT/benchmarks/bench_dense.py" $args >> "$OUT/bench_dense.jsonl" 2>> "$OUT/bench_dense.err" || exit 1
+        done
+        timeout -k 10 300 python3 "$ROOT/benchmarks/bench_two_layer.py" > "$OUT/bench_two_layer.jsonl" 2> "$OUT/bench_two_layer.err" || exit 1
+        timeout -k 10 300 python3 "$ROOT/benchmarks/bench_two_layer.py" --dropout 0.6 >> "$OUT/bench_two_layer.jsonl" 2>> "$OUT/bench_two_layer.err" || exit 1 ;;
     pmc_dense)
-        for mp in lists dense; do
+        for mp in lists dense prebuilt; do
             D="$ROOT/benchmarks/bench_dense.py --mask-path $mp --steps 2 --warmup 1"
             pmc dense_${mp}_sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- $D || exit 1
             pmc dense_${mp}_fetch FETCH_SIZE -- $D || exit 1

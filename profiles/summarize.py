@@ -79,14 +79,17 @@ def main():
         line = [l for l in open(j).read().splitlines() if l.startswith("{")][-1]
         open(os.path.join(HERE, tag + "_bench_n1.json"), "w").write(line + "\n")
     copy_stats(os.path.join(src, "stats_bench"), os.path.join(HERE, tag + "_bench_n1_kernel_stats.csv"))
-    for mp in ("lists", "dense", "csr"):
+    for mp in ("lists", "dense", "csr", "prebuilt", "lists_drop", "prebuilt_drop"):
         copy_stats(os.path.join(src, "stats_dense_" + mp), os.path.join(HERE, "%s_bench_dense_%s_kernel_stats.csv" % (tag, mp)))
+    for name in ("bench_dense.jsonl", "bench_two_layer.jsonl"):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(HERE, "%s_%s" % (tag, name)))
     sparse = counters([os.path.join(src, "pmc_" + n) for n in ("fetch", "write", "tcc", "sq")])
     write_summary(sparse, os.path.join(HERE, tag + "_bench_n1_pmc_summary.txt"),
                   "# bench.py --steps 2 --warmup 1 --no-cpu-baseline; one rocprofv3 --pmc pass per counter group; FETCH_SIZE / WRITE_SIZE in KiB")
     dense = counters(glob.glob(os.path.join(src, "pmc_dense_*")))
     write_summary(dense, os.path.join(HERE, tag + "_dense_pmc_summary.txt"),
-                  "# benchmarks/bench_dense.py --mask-path lists|dense --steps 2 --warmup 1 (configs[2]: 4096 graphs x 264 nodes)")
+                  "# benchmarks/bench_dense.py --mask-path lists|dense|prebuilt --steps 2 --warmup 1 (configs[2]: 4096 graphs x 264 nodes)")
     bnf = counters([os.path.join(src, "pmc_bnf_sq")])
     write_summary(bnf, os.path.join(HERE, tag + "_bnf_pmc_summary.txt"), "# benchmarks/bench_bnf.py (brain-network step and inner-product decoder)")
     # HBM-side traffic per launch of the sparse kernels: 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of
