@@ -48,8 +48,15 @@ class _LoopbackPeers(gdist.HaloExchange):
         self._pool = torch.empty(max(int(max(counts)), 1) * 80, dtype=torch.float32, device=device)     # a peer's rows, either direction
         gen = torch.Generator(device=device)
         gen.manual_seed(11)
-        reps = -(-n_halo // n_own)
-        self.send_idx = torch.cat([torch.randperm(n_own, device=device, generator=gen) for _ in range(reps)])[:n_halo].contiguous()
+        # what each peer reads here: a random subset of the owned rows of the size it sends, in ascending order, as the
+        # real plan lists them (a peer's halo ids are sorted): the pack gathers and the returned rows are sorted streams
+        parts = []
+        for c in self.send_counts:
+            c = int(c)
+            reps = -(-c // max(n_own, 1))
+            ids = torch.cat([torch.randperm(n_own, device=device, generator=gen) for _ in range(max(reps, 1))])[:c]
+            parts.append(torch.sort(ids).values)
+        self.send_idx = torch.cat(parts).contiguous()
         self._finish_setup()
 
     def _a2a(self, out, inp, out_splits, in_splits):

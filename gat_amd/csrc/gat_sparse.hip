@@ -557,16 +557,35 @@ __global__ __launch_bounds__(256) void gat_bwd_finalize_halo_kernel(int64_t n, c
     const float4 a2v = *reinterpret_cast<const float4 *>(a2 + sub * 4);
     const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
     for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + grp; row < n; row += stride) {
-        float4 r = *reinterpret_cast<const float4 *>(dfeat + row * HD + sub * 4);
+        const int64_t k0 = rptr[row], k1 = rptr[row + 1];
+        float4 r = load_stream4(dfeat + row * HD + sub * 4);
         float d2 = df2[row * H + head];
-        for (int64_t k = rptr[row]; k < rptr[row + 1]; ++k) {
-            const int64_t p = pos[k];
-            r = f4_add(r, *reinterpret_cast<const float4 *>(recv_feat + p * HD + sub * 4));
-            d2 += recv_df2[p * H + head];
+        const float d1 = df1[row * H + head];
+        // Up to four returned rows at a time: their positions, then all their rows, are requested together (the loads
+        // are unconditional, clamped inside the list; a row-by-row walk is a chain of dependent loads), and they are
+        // added in list order, so the sum is the one gatmi_halo_unpack_sum forms.
+        for (int64_t k = k0; k < k1; k += 4) {
+            int64_t p[4];
+            float4 v[4];
+            float e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = pos[k + u < k1 ? k + u : k1 - 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = load_stream4(recv_feat + p[u] * HD + sub * 4);
+                e[u] = recv_df2[p[u] * H + head];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k + u < k1) {
+                    r = f4_add(r, v[u]);
+                    d2 += e[u];
+                }
+            }
         }
-        r = f4_fma(df1[row * H + head], a1v, r);
+        r = f4_fma(d1, a1v, r);
         r = f4_fma(d2, a2v, r);
-        *reinterpret_cast<float4 *>(dfeat + row * HD + sub * 4) = r;
+        store_stream4(dfeat + row * HD + sub * 4, r);
         if (sub % LPH == 0) df2[row * H + head] = d2;
     }
 }
