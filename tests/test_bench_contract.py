@@ -13,7 +13,7 @@ def _line(name):
 
 
 def test_single_gpu_line_carries_the_contract():
-    d = _line("r02_bench_n1.json")
+    d = _line("r03_bench_n1.json")
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):

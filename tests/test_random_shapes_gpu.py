@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import ref_torch
-from tests.util import assert_close, dense_dropout_masks, layer_params, random_graph, sparse_dropout_masks
+from tests.util import assert_close, dense_dropout_masks, input_keep_host, layer_params, random_graph, sparse_dropout_masks
 
 pytestmark = pytest.mark.gpu
 DRAWS = int(os.environ.get("GATMI_SWEEP", "10"))
@@ -60,23 +60,27 @@ def test_sparse_layer_random_draw(seed):
     res = bool(rng.random() < 0.3) and F != D      # equal widths: the reference's residual is a no-op (layers.py:31-32)
     dst, src = random_graph(n, deg, seed=seed, hubs=hubs, hub_deg=min(n, 400))
     p = layer_params(F, H, D, seed=seed + 1, res=res)
+    coef_drop, in_drop = (float(rng.choice([0.0, 0.3, 0.6])), float(rng.choice([0.0, 0.5]))) if rng.random() < 0.35 else (0.0, 0.0)
+    # dropout of the layer's input inside the projection kernels, for the widths that allow it
+    x_drop = float(rng.choice([0.3, 0.6])) if (F % 4 == 0 and rng.random() < 0.5) else 0.0
+    xkeep = input_keep_host(4242 + seed, n, F, 1.0 - x_drop).astype(np.float64) / (1.0 - x_drop) if x_drop else 1.0
+    xmask = torch.tensor(xkeep) if x_drop else None
     x = rng.normal(0, 1, (n, F))
     for _ in range(50):
-        if _min_abs_logit(x, p, (dst, src)) > KINK:
+        if _min_abs_logit(x * xkeep, p, (dst, src)) > KINK:      # the logits are those of the input as the layer sees it
             break
         x = rng.normal(0, 1, (n, F))
     tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
-    coef_drop, in_drop = (float(rng.choice([0.0, 0.3, 0.6])), float(rng.choice([0.0, 0.5]))) if rng.random() < 0.35 else (0.0, 0.0)
-    what = "seed %d: n=%d F=%d H=%d D=%d deg=%.1f hubs=%d chunk=%d %s/%s res=%s drop=%.1f/%.1f" % (
-        seed, n, F, H, D, deg, hubs, chunk, activation, reduce, res, coef_drop, in_drop)
-    cfg = ops.make_cfg(H, D, activation, reduce, coef_drop=coef_drop, in_drop=in_drop, training=True, seed=4242 + seed)
+    what = "seed %d: n=%d F=%d H=%d D=%d deg=%.1f hubs=%d chunk=%d %s/%s res=%s drop=%.1f/%.1f x_drop=%.1f" % (
+        seed, n, F, H, D, deg, hubs, chunk, activation, reduce, res, coef_drop, in_drop, x_drop)
+    cfg = ops.make_cfg(H, D, activation, reduce, coef_drop=coef_drop, in_drop=in_drop, training=True, seed=4242 + seed, x_drop=x_drop)
     graph = CSRGraph.from_coo(dst, src, n, dev, chunk=chunk)
     rowptr, col = ref_numpy.coo_to_csr(np.stack([dst, src], 1), n)
     coef_mask, ft_mask = sparse_dropout_masks(4242 + seed, len(col), n, H, D, cfg.dp, coef_drop, in_drop)
     rp = _oracle_params(p)
 
     def oracle(rx, act):
-        return ref_torch.layer_csr(rx, rp, torch.tensor(rowptr), torch.tensor(col), act, reduce, residual=res,
+        return ref_torch.layer_csr(rx if xmask is None else rx * xmask, rp, torch.tensor(rowptr), torch.tensor(col), act, reduce, residual=res,
                                    coef_mask=None if coef_mask is None else torch.tensor(coef_mask),
                                    ft_mask=None if ft_mask is None else torch.tensor(ft_mask),
                                    coef_keep=1.0 - coef_drop, ft_keep=1.0 - in_drop)
@@ -87,7 +91,7 @@ def test_sparse_layer_random_draw(seed):
         for _ in range(50):
             with torch.no_grad():
                 pre = oracle(torch.tensor(x, dtype=torch.float64), "identity")
-            if float(pre.abs().min()) > RELU_KINK and _min_abs_logit(x, p, (dst, src)) > KINK:
+            if float(pre.abs().min()) > RELU_KINK and _min_abs_logit(x * xkeep, p, (dst, src)) > KINK:
                 break
             x = rng.normal(0, 1, (n, F))
     xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
@@ -157,6 +161,68 @@ def test_dense_layer_random_draw(seed):
         _close(xt.grad.cpu().numpy(), rx.grad.numpy(), what + " dX", atol_scale=5e-6)
         for k in ("W", "a1", "bias"):
             _close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), what + " d" + k, atol_scale=5e-6)
+
+
+@pytest.mark.parametrize("seed", range(max(1, DRAWS // 2)))
+def test_graph_resident_random_draw(seed):
+    """Batches of many small graphs (the graph-resident kernels): rows of 64 floats in every head split, graphs of
+    4..120 nodes, hard and soft masks, dropout of coefficients / projected features / the input, through the mask and —
+    for hard masks — through its prebuilt lists (bit-identical), against the float64 oracle with host-twin masks."""
+    from gat_amd import ops
+    from gat_amd.graph import MaskLists
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5000 + seed)
+    H, D = [(8, 8), (4, 16), (2, 32), (1, 64), (8, 7), (4, 13)][rng.integers(6)]
+    dp = ops.padded_width(D)
+    B = int(rng.integers(256, 300))
+    N = 4 * int(rng.integers(1, 31))
+    F = int(rng.choice([3, 8, 17, 24]))
+    density = float(rng.choice([0.05, 0.15, 0.4] if N <= 60 else [0.05, 0.15]))     # (a million logits seldom all clear the kink)
+    soft = bool(rng.random() < 0.25)
+    activation = str(rng.choice(["elu", "identity"]))
+    adj = (rng.random((B, N, N)) < density) | np.eye(N, dtype=bool)[None]
+    bm = np.where(adj, rng.normal(0, 1, (B, N, N)) if soft else 0.0, -1e9)
+    p = layer_params(F, H, D, seed=seed + 5)
+    coef_drop, in_drop = (float(rng.choice([0.0, 0.3, 0.6])), float(rng.choice([0.0, 0.5]))) if rng.random() < 0.5 else (0.0, 0.0)
+    x_drop = float(rng.choice([0.3, 0.6])) if (F % 4 == 0 and rng.random() < 0.5) else 0.0
+    sd = 999 + seed
+    coef_mask, ft_mask = dense_dropout_masks(sd, B, N, H, D, dp, coef_drop, in_drop)
+    xkeep = (input_keep_host(sd, B * N, F, 1.0 - x_drop).astype(np.float64) / (1.0 - x_drop)).reshape(B, N, F) if x_drop else 1.0
+    xmask = torch.tensor(xkeep) if x_drop else None
+    x = rng.normal(0, 1, (B, N, F))
+    bb, ii, jj = np.nonzero(adj)
+    for _ in range(200):
+        if _min_abs_logit(x * xkeep, p, (bb * N + ii, bb * N + jj)) > KINK:
+            break
+        x = rng.normal(0, 1, (B, N, F))
+    else:
+        pytest.skip("no draw clear of LeakyReLU's kink")
+    what = "seed %d: B=%d N=%d F=%d H=%d D=%d density=%.2f soft=%s %s drop=%.1f/%.1f x_drop=%.1f" % (
+        seed, B, N, F, H, D, density, soft, activation, coef_drop, in_drop, x_drop)
+    bt = torch.tensor(bm, dtype=torch.float32, device=dev)
+    rp = _oracle_params(p)
+    rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = ref_torch.layer_dense(rx if xmask is None else rx * xmask, rp, torch.tensor(bm), activation, "concat",
+                                coef_mask=None if coef_mask is None else torch.tensor(coef_mask),
+                                ft_mask=None if ft_mask is None else torch.tensor(ft_mask),
+                                coef_keep=1.0 - coef_drop, ft_keep=1.0 - in_drop)
+    dout = rng.normal(0, 1, tuple(ref.shape))
+    ref.backward(torch.tensor(dout))
+    results = []
+    for mask in ([bt] if soft else [bt, MaskLists(bt)]):
+        tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+        xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
+        cfg = ops.make_cfg(H, D, activation, mask_path="lists", coef_drop=coef_drop, in_drop=in_drop, training=True, seed=sd, x_drop=x_drop)
+        out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], mask, cfg)
+        out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
+        assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), what=what + " forward")
+        _close(xt.grad.cpu().numpy(), rx.grad.numpy(), what + " dX", atol_scale=5e-6)
+        for k in ("W", "a1", "a2", "bias"):
+            _close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), what + " d" + k, atol_scale=5e-6)
+        results.append([out.detach(), xt.grad] + [tp[k].grad for k in ("W", "a1", "a2", "b1", "b2", "bias")])
+    if len(results) == 2 and D == dp:          # (a padded head width changes nothing either, but keep the claim to the plain shapes)
+        for a, b in zip(*results):
+            assert torch.equal(a, b), what + ": prebuilt lists differ from the mask route"
 
 
 @pytest.mark.parametrize("seed", range(max(1, DRAWS // 2)))
