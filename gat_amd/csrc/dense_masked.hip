@@ -608,9 +608,13 @@ struct MRowState8 {
 // DROP: coefficient dropout (utils/layers.py:20) per (entry, head) from the counter hash; `cbase` is the hash index of
 // column 0 of this lane's (row, head), an entry's index is cbase + j * H.  Feature dropout (:22) needs nothing here:
 // the rows in LDS were dropped when they were staged.
+// wha / whb: this lane's two float4 pieces of row 0 (acc0 / pos0 belong to the first, acc1 / pos1 to the second).
+// Which piece is read first can alternate between neighbouring rows of the octet (walk_pieces): a ds_read_b128
+// serves sixteen lanes at a time, among them the same four lane slots of two different rows, and with one order for
+// all their 16-byte pieces fall on the same banks (every row starts at bank 0): two LDS cycles instead of one.
 template <int LPH8, bool SAVE, bool SOFT, bool DROP>
 __device__ __forceinline__ void graph_fwd_batch8_ids(MRowState8 &st, float slope, const int (&j)[kGraphBatch], const float *bm, int N,
-                                                     const float *whs, const float *f2s, float f1v,
+                                                     const float *wha, const float *whb, const float *f2s, float f1v,
                                                      uint64_t seed, uint64_t cbase, float coef_keep) {
     constexpr int H = 8 / LPH8;
     constexpr int HD = 64;
@@ -620,8 +624,8 @@ __device__ __forceinline__ void graph_fwd_batch8_ids(MRowState8 &st, float slope
 #pragma unroll
     for (int t = 0; t < U; ++t) {
         z[t] = f1v + f2s[j[t] * H];
-        v0[t] = *reinterpret_cast<const float4 *>(whs + j[t] * HD);
-        v1[t] = *reinterpret_cast<const float4 *>(whs + j[t] * HD + 4);
+        v0[t] = *reinterpret_cast<const float4 *>(wha + j[t] * HD);
+        v1[t] = *reinterpret_cast<const float4 *>(whb + j[t] * HD);
         if (SOFT) e[t] = bm[min(j[t], N - 1)];
     }
     float mn = st.m;
@@ -666,11 +670,29 @@ __device__ __forceinline__ void graph_fwd_batch8_ids(MRowState8 &st, float slope
 
 template <int LPH8, bool SAVE, bool SOFT, bool DROP>
 __device__ __forceinline__ void graph_fwd_batch8(MRowState8 &st, float slope, const uint16_t *lp, const float *bm, int N,
-                                                 const float *whs, const float *f2s, float f1v,
+                                                 const float *wha, const float *whb, const float *f2s, float f1v,
                                                  uint64_t seed, uint64_t cbase, float coef_keep) {
     int j[kGraphBatch];
     load_ids<kGraphBatch>(lp, j);
-    graph_fwd_batch8_ids<LPH8, SAVE, SOFT, DROP>(st, slope, j, bm, N, whs, f2s, f1v, seed, cbase, coef_keep);
+    graph_fwd_batch8_ids<LPH8, SAVE, SOFT, DROP>(st, slope, j, bm, N, wha, whb, f2s, f1v, seed, cbase, coef_keep);
+}
+
+__device__ __forceinline__ void row_state_reset(MRowState8 &st, float m) {
+    st.m = m;
+    st.s = st.q = 0.f;
+    st.acc0 = st.acc1 = st.pos0 = st.pos1 = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Offsets (in floats, within a lane's eight) of the piece a lane of the walk reads first and second: lanes whose
+// bit `bit` is set take the upper piece first.  bit 3 for eight lanes per row (the rows of an octet alternate),
+// bit 2 for four lanes per column.
+// Measured at 4096 graphs x 264 nodes: bank conflicts fall by four fifths (forward) and a quarter (half-row
+// backward), the second address costs 6 % more vector instructions, and the kernels take the same time or 3 % more:
+// the LDS array is not what they wait for.  Off; the walks then read one address with an immediate offset.
+constexpr bool kAlternatePieces = false;
+__device__ __forceinline__ void walk_pieces(int lane, int bit, int &first, int &second) {
+    first = kAlternatePieces ? ((lane >> bit) & 1) * 4 : 0;
+    second = 4 - first;
 }
 
 constexpr int kGraphWalkRows = 8;          // rows per wave in the eight-lane walk
@@ -756,7 +778,10 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_fwd8_kernel(
     // walk geometry: row r8 of the octet, lane s8 of the row
     const int r8 = lane >> 3, s8 = lane & 7;
     const int head8 = s8 / LPH8;
-    const float *whl = whs + s8 * 8;
+    int pa, pb;
+    walk_pieces(lane, 3, pa, pb);
+    const int oa = s8 * 8 + pa, ob = s8 * 8 + pb;        // columns of this lane's first and second piece
+    const float *wha = whs + oa, *whb = whs + ob;
     const float *f2l = f2s + head8;
     for (; oct0 < N; oct0 += nwaves * kGraphWalkRows) {
         bool anysoft = false;
@@ -841,17 +866,15 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_fwd8_kernel(
         const float f1v = a.f1[(b * N + i) * H + head8];
         const uint64_t cbase = DROP ? ((uint64_t)(b * N + i) * (uint64_t)N) * H + head8 : 0;
         MRowState8 st;
-        st.m = -INFINITY;
-        st.s = st.q = 0.f;
-        st.acc0 = st.acc1 = st.pos0 = st.pos1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        row_state_reset(st, -INFINITY);
         {
             const float *bm_own = LISTS ? nullptr : bmat + i * N;
             if (!LISTS && anysoft) {                      // wave-uniform: biases are fetched for all of the wave's rows
                 for (int k = 0; k < total; k += kGraphBatch)
-                    graph_fwd_batch8<LPH8, SAVE, !LISTS, DROP>(st, a.slope, lrow + k, bm_own, N, whl, f2l, f1v, seed, cbase, a.coef_keep);
+                    graph_fwd_batch8<LPH8, SAVE, !LISTS, DROP>(st, a.slope, lrow + k, bm_own, N, wha, whb, f2l, f1v, seed, cbase, a.coef_keep);
             } else {
                 for (int k = 0; k < total; k += kGraphBatch)
-                    graph_fwd_batch8<LPH8, SAVE, false, DROP>(st, a.slope, lrow + k, bm_own, N, whl, f2l, f1v, seed, cbase, a.coef_keep);
+                    graph_fwd_batch8<LPH8, SAVE, false, DROP>(st, a.slope, lrow + k, bm_own, N, wha, whb, f2l, f1v, seed, cbase, a.coef_keep);
             }
         }
         if constexpr (!LISTS) __builtin_amdgcn_wave_barrier();   // every lane is done with the lists before the next rows overwrite them
@@ -862,12 +885,12 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_fwd8_kernel(
             const float4 ag0 = f4_scale(inv, st.acc0), ag1 = f4_scale(inv, st.acc1);
             float *o = nullptr;
             if (SAVE) {
-                o = a.agg + row * HD + s8 * 8;
-                store_stream4(o, ag0);
-                store_stream4(o + 4, ag1);
-                o = a.pos + row * HD + s8 * 8;
-                store_stream4(o, f4_scale(inv, st.pos0));
-                store_stream4(o + 4, f4_scale(inv, st.pos1));
+                o = a.agg + row * HD;
+                store_stream4(o + oa, ag0);
+                store_stream4(o + ob, ag1);
+                o = a.pos + row * HD;
+                store_stream4(o + oa, f4_scale(inv, st.pos0));
+                store_stream4(o + ob, f4_scale(inv, st.pos1));
                 if (s8 % LPH8 == 0) {
                     a.lse[row * H + head8] = empty ? 0.f : st.m + logf(st.s);
                     a.q[row * H + head8] = st.q * inv;
@@ -875,20 +898,20 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_fwd8_kernel(
             }
             float4 r0 = ag0, r1 = ag1;
             if (a.bias) {
-                r0 = f4_add(r0, *reinterpret_cast<const float4 *>(a.bias + s8 * 8));
-                r1 = f4_add(r1, *reinterpret_cast<const float4 *>(a.bias + s8 * 8 + 4));
+                r0 = f4_add(r0, *reinterpret_cast<const float4 *>(a.bias + oa));
+                r1 = f4_add(r1, *reinterpret_cast<const float4 *>(a.bias + ob));
             }
             if (a.resid) {
-                r0 = f4_add(r0, *reinterpret_cast<const float4 *>(a.resid + row * HD + s8 * 8));
-                r1 = f4_add(r1, *reinterpret_cast<const float4 *>(a.resid + row * HD + s8 * 8 + 4));
+                r0 = f4_add(r0, *reinterpret_cast<const float4 *>(a.resid + row * HD + oa));
+                r1 = f4_add(r1, *reinterpret_cast<const float4 *>(a.resid + row * HD + ob));
             }
             if (a.activation != GATMI_ACT_IDENTITY) {
                 r0 = make_float4(act_f(r0.x, a.activation), act_f(r0.y, a.activation), act_f(r0.z, a.activation), act_f(r0.w, a.activation));
                 r1 = make_float4(act_f(r1.x, a.activation), act_f(r1.y, a.activation), act_f(r1.z, a.activation), act_f(r1.w, a.activation));
             }
-            o = a.out + row * HD + s8 * 8;
-            store_stream4(o, r0);
-            store_stream4(o + 4, r1);
+            o = a.out + row * HD;
+            store_stream4(o + oa, r0);
+            store_stream4(o + ob, r1);
         }
     }
 }
@@ -946,7 +969,10 @@ __global__ __launch_bounds__(64 * kGraph8ListsWaves, 2) void dense_graph_fwd8_li
     __syncthreads();
     const int r8 = lane >> 3, s8 = lane & 7;
     const int head8 = s8 / LPH8;
-    const float *whl = whs + s8 * 8;
+    int pa, pb;
+    walk_pieces(lane, 3, pa, pb);
+    const int oa = s8 * 8 + pa, ob = s8 * 8 + pb;        // columns of this lane's first and second piece
+    const float *wha = whs + oa, *whb = whs + ob;
     const float *f2l = f2s + head8;
     const uint16_t *gcol = a.lcol + base;
     const uint32_t dummy = (uint32_t)N | ((uint32_t)N << 16);      // the zero row (Wh = 0, f2 = -inf: coefficient exactly 0)
@@ -982,9 +1008,7 @@ __global__ __launch_bounds__(64 * kGraph8ListsWaves, 2) void dense_graph_fwd8_li
         const float f1v = a.f1[(b * N + i) * H + head8];
         const uint64_t cbase = DROP ? ((uint64_t)(b * N + i) * (uint64_t)N) * H + head8 : 0;
         MRowState8 st;
-        st.m = -INFINITY;
-        st.s = st.q = 0.f;
-        st.acc0 = st.acc1 = st.pos0 = st.pos1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        row_state_reset(st, -INFINITY);
         for (int c0 = 0; __any(c0 < total); c0 += 32) {
             if (c0 > 0) ch = fetch(o0, total, c0);                  // lists of more than 32 entries: further chunks as they come
 #pragma unroll
@@ -992,7 +1016,7 @@ __global__ __launch_bounds__(64 * kGraph8ListsWaves, 2) void dense_graph_fwd8_li
                 if (!__any(c0 + 4 * t < total)) break;              // wave-uniform
                 const uint32_t w0 = (uint32_t)__shfl((int)ch.x, lane0 + t, 64), w1 = (uint32_t)__shfl((int)ch.y, lane0 + t, 64);
                 const int j[kGraphBatch] = {(int)(w0 & 0xffff), (int)(w0 >> 16), (int)(w1 & 0xffff), (int)(w1 >> 16)};
-                graph_fwd_batch8_ids<LPH8, SAVE, false, DROP>(st, a.slope, j, nullptr, N, whl, f2l, f1v, seed, cbase, a.coef_keep);
+                graph_fwd_batch8_ids<LPH8, SAVE, false, DROP>(st, a.slope, j, nullptr, N, wha, whb, f2l, f1v, seed, cbase, a.coef_keep);
             }
         }
         if (row_ok) {
@@ -1002,12 +1026,12 @@ __global__ __launch_bounds__(64 * kGraph8ListsWaves, 2) void dense_graph_fwd8_li
             const float4 ag0 = f4_scale(inv, st.acc0), ag1 = f4_scale(inv, st.acc1);
             float *o = nullptr;
             if (SAVE) {
-                o = a.agg + row * HD + s8 * 8;
-                store_stream4(o, ag0);
-                store_stream4(o + 4, ag1);
-                o = a.pos + row * HD + s8 * 8;
-                store_stream4(o, f4_scale(inv, st.pos0));
-                store_stream4(o + 4, f4_scale(inv, st.pos1));
+                o = a.agg + row * HD;
+                store_stream4(o + oa, ag0);
+                store_stream4(o + ob, ag1);
+                o = a.pos + row * HD;
+                store_stream4(o + oa, f4_scale(inv, st.pos0));
+                store_stream4(o + ob, f4_scale(inv, st.pos1));
                 if (s8 % LPH8 == 0) {
                     a.lse[row * H + head8] = empty ? 0.f : st.m + logf(st.s);
                     a.q[row * H + head8] = st.q * inv;
@@ -1015,20 +1039,20 @@ __global__ __launch_bounds__(64 * kGraph8ListsWaves, 2) void dense_graph_fwd8_li
             }
             float4 r0 = ag0, r1 = ag1;
             if (a.bias) {
-                r0 = f4_add(r0, *reinterpret_cast<const float4 *>(a.bias + s8 * 8));
-                r1 = f4_add(r1, *reinterpret_cast<const float4 *>(a.bias + s8 * 8 + 4));
+                r0 = f4_add(r0, *reinterpret_cast<const float4 *>(a.bias + oa));
+                r1 = f4_add(r1, *reinterpret_cast<const float4 *>(a.bias + ob));
             }
             if (a.resid) {
-                r0 = f4_add(r0, *reinterpret_cast<const float4 *>(a.resid + row * HD + s8 * 8));
-                r1 = f4_add(r1, *reinterpret_cast<const float4 *>(a.resid + row * HD + s8 * 8 + 4));
+                r0 = f4_add(r0, *reinterpret_cast<const float4 *>(a.resid + row * HD + oa));
+                r1 = f4_add(r1, *reinterpret_cast<const float4 *>(a.resid + row * HD + ob));
             }
             if (a.activation != GATMI_ACT_IDENTITY) {
                 r0 = make_float4(act_f(r0.x, a.activation), act_f(r0.y, a.activation), act_f(r0.z, a.activation), act_f(r0.w, a.activation));
                 r1 = make_float4(act_f(r1.x, a.activation), act_f(r1.y, a.activation), act_f(r1.z, a.activation), act_f(r1.w, a.activation));
             }
-            o = a.out + row * HD + s8 * 8;
-            store_stream4(o, r0);
-            store_stream4(o + 4, r1);
+            o = a.out + row * HD;
+            store_stream4(o + oa, r0);
+            store_stream4(o + ob, r1);
         }
         i = in; o0 = on; total = tn; ch = chn;
     }
@@ -1400,29 +1424,41 @@ struct MSrcState8 {
     float df2;
 };
 
+// <a, b> over eight floats as four packed two-float multiply-adds and one add.  Written on two-float vectors so
+// that the products of ONE entry share the packed instructions: left to itself the compiler pairs the products of
+// two entries instead and spends two register moves per packed instruction on bringing their operands together.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot8_pairs(float4 a0, float4 a1, float4 b0, float4 b1) {
+    f32x2 s = (f32x2){a0.x, a0.y} * (f32x2){b0.x, b0.y};
+    s = __builtin_elementwise_fma((f32x2){a0.z, a0.w}, (f32x2){b0.z, b0.w}, s);
+    s = __builtin_elementwise_fma((f32x2){a1.x, a1.y}, (f32x2){b1.x, b1.y}, s);
+    s = __builtin_elementwise_fma((f32x2){a1.z, a1.w}, (f32x2){b1.z, b1.w}, s);
+    return s.x + s.y;
+}
+
 // DROP: coefficient dropout per (entry, head); `cbase` is the hash index of destination row 0 for this lane's
 // (column, head), an entry's index is cbase + i * (N * H).  wh0 / wh1 already carry the feature mask.
-template <int LPH8, bool SOFT, bool DROP>
-__device__ __forceinline__ void graph_bwd_batch8(MSrcState8 &st, float slope, const uint16_t *lp, const float *bmcol, int N,
-                                                 const float *gs, const float *ss, float f2v, float4 wh0, float4 wh1,
-                                                 uint64_t seed, uint64_t cbase, float coef_keep) {
+// ga / gb: this lane's two float4 pieces of g row 0, in the order walk_pieces gives them (wh0 / acc0 belong to the
+// first, wh1 / acc1 to the second).  GS / HS: floats of a g row and heads of a statistics row as the block keeps them in LDS (the whole row, or the
+// half of it that dense_graph_bwd8_half_kernel holds); the dropout hash always counts the layer's H heads.
+template <int LPH8, bool SOFT, bool DROP, int GS = 64, int HS = 8 / LPH8>
+__device__ __forceinline__ void graph_bwd_batch8_ids(MSrcState8 &st, float slope, int (&i)[kGraphBatch], const float *bmcol, int N,
+                                                     const float *ga, const float *gb, const float *ss, float f2v, float4 wh0, float4 wh1,
+                                                     uint64_t seed, uint64_t cbase, float coef_keep) {
     constexpr int H = 8 / LPH8;
-    constexpr int HD = 64;
     constexpr int U = kGraphBatch;
-    int i[U];
     float4 g0[U], g1[U];
     float f1v[U], lsev[U], cv[U], bv[U];
-    load_ids<U>(lp, i);                                  // entries: row id | (needs its bias value) << 15
 #pragma unroll
-    for (int t = 0; t < U; ++t) {
+    for (int t = 0; t < U; ++t) {                        // entries: row id | (needs its bias value) << 15
         const bool soft = i[t] & 0x8000;
         i[t] &= 0x7fff;
-        g0[t] = *reinterpret_cast<const float4 *>(gs + i[t] * HD);
-        g1[t] = *reinterpret_cast<const float4 *>(gs + i[t] * HD + 4);
-        const float *sp = ss + i[t] * (3 * H);
+        g0[t] = *reinterpret_cast<const float4 *>(ga + i[t] * GS);
+        g1[t] = *reinterpret_cast<const float4 *>(gb + i[t] * GS);
+        const float *sp = ss + i[t] * (3 * HS);
         f1v[t] = sp[0];
-        lsev[t] = sp[H];
-        cv[t] = sp[2 * H];
+        lsev[t] = sp[HS];
+        cv[t] = sp[2 * HS];
         bv[t] = 0.f;
         if (SOFT) {
             if (soft) bv[t] = bmcol[(uint32_t)min(i[t], N - 1) * (uint32_t)N];
@@ -1435,7 +1471,7 @@ __device__ __forceinline__ void graph_bwd_batch8(MSrcState8 &st, float slope, co
     for (int t = 0; t < U; ++t) {
         const float z = f1v[t] + f2v;
         const float alpha = exp_neg((SOFT ? leaky(z, slope) + bv[t] : leaky(z, slope)) - lsev[t]);
-        float dalpha = group_sum<LPH8>(dot4(g0[t], wh0) + dot4(g1[t], wh1));
+        float dalpha = group_sum<LPH8>(dot8_pairs(g0[t], g1[t], wh0, wh1));
         float aa = alpha;
         if (DROP) {
             if (coef_keep < 1.f) {
@@ -1451,6 +1487,15 @@ __device__ __forceinline__ void graph_bwd_batch8(MSrcState8 &st, float slope, co
     st.acc0 = f4_add(st.acc0, bacc0);
     st.acc1 = f4_add(st.acc1, bacc1);
     st.df2 += bdf2;
+}
+
+template <int LPH8, bool SOFT, bool DROP>
+__device__ __forceinline__ void graph_bwd_batch8(MSrcState8 &st, float slope, const uint16_t *lp, const float *bmcol, int N,
+                                                 const float *ga, const float *gb, const float *ss, float f2v, float4 wh0, float4 wh1,
+                                                 uint64_t seed, uint64_t cbase, float coef_keep) {
+    int i[kGraphBatch];
+    load_ids<kGraphBatch>(lp, i);
+    graph_bwd_batch8_ids<LPH8, SOFT, DROP>(st, slope, i, bmcol, N, ga, gb, ss, f2v, wh0, wh1, seed, cbase, coef_keep);
 }
 
 // LDS: g [N + pad][64] | stats [N + pad][3H] | bits [N][W] | lists [waves][8][lc] (uint16) | entry counts [waves][8] (int)
@@ -1596,7 +1641,10 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
     }
     const int c8 = lane >> 3, s8 = lane & 7;
     const int head8 = s8 / LPH8;
-    const float *gl = gs + s8 * 8;
+    int pa, pb;
+    walk_pieces(lane, 3, pa, pb);
+    const int oa = s8 * 8 + pa, ob = s8 * 8 + pb;        // columns of this lane's first and second piece
+    const float *ga = gs + oa, *gb = gs + ob;
     const float *sl = ss + head8;
     for (int j0 = wave * kGraphWalkRows; j0 < N; j0 += nwaves * kGraphWalkRows) {
         bool anysoft = false;
@@ -1669,12 +1717,12 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
         }
         const int64_t j = b * N + jcol;
         const float f2v = a.f2[j * H + head8];
-        float4 wh0 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + s8 * 8);
-        float4 wh1 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + s8 * 8 + 4);
+        float4 wh0 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + oa);
+        float4 wh1 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + ob);
         if (DROP) {
             if (a.feat_keep < 1.f) {
-                wh0 = drop_feat(wh0, seed, j, HD, s8 * 8, a.feat_keep);
-                wh1 = drop_feat(wh1, seed, j, HD, s8 * 8 + 4, a.feat_keep);
+                wh0 = drop_feat(wh0, seed, j, HD, oa, a.feat_keep);
+                wh1 = drop_feat(wh1, seed, j, HD, ob, a.feat_keep);
             }
         }
         const uint64_t cbase = DROP ? ((uint64_t)(b * N) * (uint64_t)N + (uint64_t)jcol) * H + head8 : 0;
@@ -1685,10 +1733,10 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
             const float *bmcol = LISTS ? nullptr : a.bias_mat + b * N * (int64_t)N + jcol;
             if (!LISTS && anysoft) {
                 for (int k = 0; k < total; k += kGraphBatch)
-                    graph_bwd_batch8<LPH8, !LISTS, DROP>(st, a.slope, lrow + k, bmcol, N, gl, sl, f2v, wh0, wh1, seed, cbase, a.coef_keep);
+                    graph_bwd_batch8<LPH8, !LISTS, DROP>(st, a.slope, lrow + k, bmcol, N, ga, gb, sl, f2v, wh0, wh1, seed, cbase, a.coef_keep);
             } else {
                 for (int k = 0; k < total; k += kGraphBatch)
-                    graph_bwd_batch8<LPH8, false, DROP>(st, a.slope, lrow + k, bmcol, N, gl, sl, f2v, wh0, wh1, seed, cbase, a.coef_keep);
+                    graph_bwd_batch8<LPH8, false, DROP>(st, a.slope, lrow + k, bmcol, N, ga, gb, sl, f2v, wh0, wh1, seed, cbase, a.coef_keep);
             }
         }
         if constexpr (!LISTS) __builtin_amdgcn_wave_barrier();   // every lane is done with the lists before the next columns overwrite them
@@ -1696,21 +1744,245 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
             float4 r0 = st.acc0, r1 = st.acc1;
             if (DROP) {
                 if (a.feat_keep < 1.f) {
-                    r0 = drop_feat(r0, seed, j, HD, s8 * 8, a.feat_keep);
-                    r1 = drop_feat(r1, seed, j, HD, s8 * 8 + 4, a.feat_keep);
+                    r0 = drop_feat(r0, seed, j, HD, oa, a.feat_keep);
+                    r1 = drop_feat(r1, seed, j, HD, ob, a.feat_keep);
                 }
             }
             if (a.a1) {
                 const float d1 = (FUSED ? a.df1_out : a.df1)[j * H + head8];
-                r0 = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + s8 * 8), r0);
-                r1 = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + s8 * 8 + 4), r1);
-                r0 = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + s8 * 8), r0);
-                r1 = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + s8 * 8 + 4), r1);
+                r0 = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + oa), r0);
+                r1 = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + ob), r1);
+                r0 = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + oa), r0);
+                r1 = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + ob), r1);
             }
-            store_stream4(a.dWh + j * HD + s8 * 8, r0);
-            store_stream4(a.dWh + j * HD + s8 * 8 + 4, r1);
+            store_stream4(a.dWh + j * HD + oa, r0);
+            store_stream4(a.dWh + j * HD + ob, r1);
             if (s8 % LPH8 == 0) a.df2[j * H + head8] = st.df2;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The fused backward kernel over prebuilt lists, split by halves of the 64-float row.  Block (graph, half)
+// keeps 32 floats of every g row and the statistics of that half's heads: under 49 KB at 264 nodes, so
+// THREE blocks of four waves share a CU (the same twelve waves as one whole-row block), and one block's
+// memory phase (the per-destination step reads dOut, agg and pos of its graph) runs under the other
+// blocks' walks, where a single block per CU alternates between the two.  A column belongs to four lanes
+// of eight floats, sixteen columns to a wave; the lists are read from memory as in
+// dense_graph_fwd8_lists_kernel (a lane fetches two batches of four ids, the group passes them round),
+// columns in the order of their list lengths.  Heads must not straddle the halves: H >= 2.
+// Every (column, head) adds the same terms in the same order as dense_graph_bwd8_kernel; only the partial
+// sums of the bias gradient are grouped differently.
+// ------------------------------------------------------------------------------------------
+constexpr int kHalfFloats = 32;            // floats of a row per block
+constexpr int kHalfCols = 16;              // columns per wave in the four-lane walk
+// LDS: g [N + pad][32] | stats [N + pad][3 H/2] | max(list offsets + column order, one float4 per row-slice lane and wave)
+static inline size_t graph8_bwd_half_lds(int N, int H, int waves) {
+    return (size_t)(N + kGraphPadRows) * (kHalfFloats + 3 * (H / 2)) * sizeof(float) +
+           std::max(graph8_lists_head_lds(N), (size_t)waves * 8 * sizeof(float4));
+}
+
+// Block id -> (graph, half): workgroups are dealt round-robin over the 8 XCDs, so the two halves of a graph get
+// ids 8 apart and share one L2 for the graph's lists.  Launch ceil(B / 8) * 16 blocks; graphs past B exit.
+__device__ __forceinline__ void graph_and_half(int64_t &graph, int &half) {
+    const int64_t L = blockIdx.x;
+    half = (int)((L >> 3) & 1);
+    graph = (L >> 4) * 8 + (L & 7);
+}
+
+template <int LPH8, int WAVES, bool DROP>
+__global__ __launch_bounds__(64 * WAVES, 12 / WAVES) void dense_graph_bwd8_half_kernel(MaskedBwdArgs a) {
+    static_assert(LPH8 == 1 || LPH8 == 2 || LPH8 == 4, "a half row holds whole heads");
+    constexpr int H = 8 / LPH8;            // heads of the layer
+    constexpr int HB = H / 2;              // heads of this block
+    constexpr int HD = 64, HW = kHalfFloats;
+    constexpr int SS = 3 * HB;             // statistics per row: {f1, lse, c} of each head
+    extern __shared__ __attribute__((aligned(16))) unsigned char graph_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int N = a.N;
+    const int NP = N + kGraphPadRows;
+    int64_t b;
+    int hf;
+    graph_and_half(b, hf);
+    if (b >= a.B) return;
+    float *gs = reinterpret_cast<float *>(graph_smem);                        // [NP][HW]
+    float *ss = gs + NP * HW;                                                 // [NP][SS]
+    unsigned char *area = reinterpret_cast<unsigned char *>(ss + NP * SS);
+    int *off_s = reinterpret_cast<int *>(area);
+    uint16_t *ord_s = reinterpret_cast<uint16_t *>(off_s + ((N + 2) & ~1));
+    const uint64_t seed = DROP ? seed_now(a) : 0;
+    {
+        // the per-destination step (see dense_graph_bwd8_kernel), eight lanes of one float4 per row slice
+        constexpr int LPH = 2 * LPH8;                   // float4 lanes per head
+        const int sub = lane & 7, rg = lane >> 3;
+        const int headl = sub / LPH, head = hf * HB + headl;
+        const int col = hf * HW + sub * 4;
+        const float4 biasv = a.bias ? *reinterpret_cast<const float4 *>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int SR = 4;                           // row slices whose loads are issued together
+        for (int r0 = wave * 8 + rg; r0 < NP; r0 += SR * WAVES * 8) {
+            float4 dv[SR], av[SR], pv[SR], ov[SR];
+#pragma unroll
+            for (int u = 0; u < SR; ++u) {
+                const int64_t row = b * N + min(r0 + u * WAVES * 8, N - 1);
+                dv[u] = load_stream4(a.dout + row * HD + col);
+                av[u] = load_stream4(a.agg + row * HD + col);
+                pv[u] = load_stream4(a.pos + row * HD + col);
+                ov[u] = a.out ? *reinterpret_cast<const float4 *>(a.out + row * HD + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < SR; ++u) {
+                const int r = r0 + u * WAVES * 8;
+                if (r >= NP) break;
+                float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+                float f1v = 0.f, lsev = INFINITY, c = 0.f;      // dummy rows: coefficient exactly 0
+                if (r < N) {
+                    const int64_t row = b * N + r;
+                    gv = dv[u];
+                    const float4 ag = av[u], po = pv[u];
+                    if (a.activation != GATMI_ACT_IDENTITY) {
+                        if (a.out) {
+                            gv.x *= act_grad_from_out(ov[u].x, a.activation);
+                            gv.y *= act_grad_from_out(ov[u].y, a.activation);
+                            gv.z *= act_grad_from_out(ov[u].z, a.activation);
+                            gv.w *= act_grad_from_out(ov[u].w, a.activation);
+                        } else {
+                            const float4 pre = f4_add(ag, biasv);
+                            gv.x *= act_grad_from_pre(pre.x, a.activation);
+                            gv.y *= act_grad_from_pre(pre.y, a.activation);
+                            gv.z *= act_grad_from_pre(pre.z, a.activation);
+                            gv.w *= act_grad_from_pre(pre.w, a.activation);
+                        }
+                    }
+                    c = group_sum<LPH>(dot4(gv, ag));
+                    const float gp = group_sum<LPH>(dot4(gv, po));
+                    f1v = a.f1[row * H + head];
+                    lsev = a.lse[row * H + head];
+                    if (sub % LPH == 0) a.df1_out[row * H + head] = (1.0f - a.slope) * (gp - c * a.q[row * H + head]);
+                    if (a.g_out) store_stream4(a.g_out + row * HD + col, gv);
+                    gsum = f4_add(gsum, gv);
+                }
+                *reinterpret_cast<float4 *>(gs + r * HW + sub * 4) = gv;
+                if (sub % LPH == 0) {
+                    ss[r * SS + headl] = f1v;
+                    ss[r * SS + HB + headl] = lsev;
+                    ss[r * SS + 2 * HB + headl] = c;
+                }
+            }
+        }
+        if (a.dbias_ws) {
+            // column sums of g over the block in a fixed order: the eight row groups of a wave, then the waves
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                gsum.x += __shfl_xor(gsum.x, o, 64);
+                gsum.y += __shfl_xor(gsum.y, o, 64);
+                gsum.z += __shfl_xor(gsum.z, o, 64);
+                gsum.w += __shfl_xor(gsum.w, o, 64);
+            }
+            float4 *red = reinterpret_cast<float4 *>(area);
+            if (lane < 8) red[wave * 8 + lane] = gsum;
+            __syncthreads();
+            if (threadIdx.x < 8) {
+                float4 t = red[threadIdx.x];
+                for (int w = 1; w < WAVES; ++w) t = f4_add(t, red[w * 8 + threadIdx.x]);
+                *reinterpret_cast<float4 *>(a.dbias_ws + b * HD + hf * HW + threadIdx.x * 4) = t;
+            }
+            __syncthreads();                              // the area is free for the list offsets
+        }
+    }
+    const int32_t base = a.lptr[b * N];
+    for (int r = threadIdx.x; r <= N; r += 64 * WAVES) off_s[r] = a.lptr[b * N + r] - base;
+    for (int r = threadIdx.x; r < N; r += 64 * WAVES) ord_s[r] = a.lord[b * N + r];
+    __syncthreads();
+    const int c4 = lane >> 2, s4 = lane & 3;
+    const int headl = s4 / LPH8, head = hf * HB + headl;
+    // (walk_pieces: neighbouring columns may take their two pieces in opposite order.  The four columns that one LDS
+    // cycle serves read rows that start on one of two bank halves at random: with one order for all, four columns
+    // share two sixteen-bank sets, 2.75 cycles on average; alternating, 1.75.)
+    int pa, pb;
+    walk_pieces(lane, 2, pa, pb);
+    const int la = s4 * 8 + pa, lb = s4 * 8 + pb;          // within the half row
+    const int oa = hf * HW + la, ob = hf * HW + lb;        // within the whole row
+    const float *ga = gs + la, *gb = gs + lb;
+    const float *sl = ss + headl;
+    const uint16_t *gcol = a.lcol + base;
+    const uint32_t dummy = (uint32_t)N | ((uint32_t)N << 16);      // the dummy row: lse = +inf, coefficient exactly 0
+    const int lane0 = lane & 60;                                    // first lane of this column's group
+    // batches s4 and 4 + s4 of the eight that start at entry c0 of a column's list; past the list: the dummy id.
+    // The loads are unconditional (clamped inside the list) so that the request for the NEXT columns stays in
+    // flight across the walk of the current ones.
+    auto fetch = [&](int o0, int total, int c0) -> uint4 {
+        const int at0 = c0 + 4 * s4, at1 = at0 + 16;
+        const int last = max(total - 4, 0);
+        const uint2 v0 = *reinterpret_cast<const uint2 *>(gcol + o0 + min(at0, last));
+        const uint2 v1 = *reinterpret_cast<const uint2 *>(gcol + o0 + min(at1, last));
+        return make_uint4(at0 < total ? v0.x : dummy, at0 < total ? v0.y : dummy, at1 < total ? v1.x : dummy, at1 < total ? v1.y : dummy);
+    };
+    auto columns = [&](int j0, int &jcol, int &o0, int &total) {
+        jcol = ord_s[min(j0 + c4, N - 1)];
+        o0 = off_s[jcol];
+        total = j0 + c4 < N ? off_s[jcol + 1] - o0 : 0;
+    };
+    int j0 = wave * kHalfCols;
+    int jcol = 0, o0 = 0, total = 0;
+    uint4 ch = make_uint4(dummy, dummy, dummy, dummy);
+    if (j0 < N) {
+        columns(j0, jcol, o0, total);
+        ch = fetch(o0, total, 0);
+    }
+    for (; j0 < N; j0 += WAVES * kHalfCols) {
+        const int jn0 = j0 + WAVES * kHalfCols;
+        int jn, on, tn;
+        columns(min(jn0, N - 1), jn, on, tn);                       // past the graph: the clamped column, never walked
+        if (jn0 >= N) tn = 0;
+        const uint4 chn = fetch(on, tn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool col_ok = j0 + c4 < N;
+        const int64_t j = b * N + jcol;
+        const float f2v = a.f2[j * H + head];
+        float4 wh0 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + oa);
+        float4 wh1 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + ob);
+        if (DROP) {
+            if (a.feat_keep < 1.f) {
+                wh0 = drop_feat(wh0, seed, j, HD, oa, a.feat_keep);
+                wh1 = drop_feat(wh1, seed, j, HD, ob, a.feat_keep);
+            }
+        }
+        const uint64_t cbase = DROP ? ((uint64_t)(b * N) * (uint64_t)N + (uint64_t)jcol) * H + head : 0;
+        MSrcState8 st;
+        st.acc0 = st.acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.df2 = 0.f;
+        for (int c0 = 0; __any(c0 < total); c0 += 32) {
+            if (c0 > 0) ch = fetch(o0, total, c0);                  // lists of more than 32 entries: further chunks as they come
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (!__any(c0 + 4 * t < total)) break;              // wave-uniform
+                const uint32_t w0 = (uint32_t)__shfl((int)(t < 4 ? ch.x : ch.z), lane0 + (t & 3), 64);
+                const uint32_t w1 = (uint32_t)__shfl((int)(t < 4 ? ch.y : ch.w), lane0 + (t & 3), 64);
+                int i[kGraphBatch] = {(int)(w0 & 0xffff), (int)(w0 >> 16), (int)(w1 & 0xffff), (int)(w1 >> 16)};
+                graph_bwd_batch8_ids<LPH8, false, DROP, HW, HB>(st, a.slope, i, nullptr, N, ga, gb, sl, f2v, wh0, wh1, seed, cbase, a.coef_keep);
+            }
+        }
+        if (col_ok) {
+            float4 r0 = st.acc0, r1 = st.acc1;
+            if (DROP) {
+                if (a.feat_keep < 1.f) {
+                    r0 = drop_feat(r0, seed, j, HD, oa, a.feat_keep);
+                    r1 = drop_feat(r1, seed, j, HD, ob, a.feat_keep);
+                }
+            }
+            if (a.a1) {
+                const float d1 = a.df1_out[j * H + head];
+                r0 = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + oa), r0);
+                r1 = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + ob), r1);
+                r0 = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + oa), r0);
+                r1 = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + ob), r1);
+            }
+            store_stream4(a.dWh + j * HD + oa, r0);
+            store_stream4(a.dWh + j * HD + ob, r1);
+            if (s4 % LPH8 == 0) a.df2[j * H + head] = st.df2;
+        }
+        jcol = jn; o0 = on; total = tn; ch = chn;
     }
 }
 
@@ -1894,6 +2166,30 @@ static int launch_graph_bwd8_fused(const MaskedBwdArgs &a, int LPH, bool drop, s
     return fail(GATMI_EUNSUPPORTED, "%s: no kernel for %d lanes per head", name, LPH);
 }
 
+constexpr int kHalfWaves = 4;              // three blocks per CU: twelve waves, 168 registers per lane (six waves x two blocks measured slower)
+static int launch_graph_bwd8_half(const MaskedBwdArgs &a, int LPH, bool drop, hipStream_t st, const char *name) {
+    const int H = 16 / LPH;
+    const size_t lds = graph8_bwd_half_lds(a.N, H, kHalfWaves);
+    const unsigned blocks = (unsigned)((a.B + 7) / 8 * 16);
+    hipError_t e = hipSuccess;
+#define GATMI_L(ll, dr)                                                                                              \
+    {                                                                                                                \
+        if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_graph_bwd8_half_kernel<ll, kHalfWaves, dr>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL((dense_graph_bwd8_half_kernel<ll, kHalfWaves, dr>), dim3(blocks), dim3(64 * kHalfWaves), lds, st, a); \
+    }
+#define X(ll)                                                                                                        \
+    if (LPH == 2 * ll) {                                                                                            \
+        if (drop) GATMI_L(ll, true) else GATMI_L(ll, false)                                                          \
+        if (e != hipSuccess) return fail(GATMI_EHIP, "%s: %s", name, hipGetErrorString(e));                         \
+        GATMI_LAUNCH_CHECK(name);                                                                                   \
+        return GATMI_OK;                                                                                            \
+    }
+    X(1) X(2) X(4)
+#undef X
+#undef GATMI_L
+    return fail(GATMI_EUNSUPPORTED, "%s: no kernel for %d lanes per head", name, LPH);
+}
+
 static int masked_check(int64_t B, int32_t N, int32_t H, int32_t dp, int *G, int *LPH, const char *name) {
     int rc = check_shape(H, dp, G, LPH);
     if (rc) return rc;
@@ -2060,6 +2356,8 @@ extern "C" int64_t gatmi_dense_lists_capacity(int32_t N, int32_t H, int32_t dp, 
     const size_t limit = graph_lds_limit();
     if (!backward)                                       // the forward kernel reads its lists from memory: any length, if the rows fit
         return graph8_fwd_walk_lds(N, H) <= limit ? (int64_t)(N + kGraphBatch) * N : 0;
+    if (H >= 2)                                          // half-row blocks read their lists from memory as well
+        return graph8_bwd_half_lds(N, H, kHalfWaves) <= limit ? (int64_t)(N + kGraphBatch) * N : 0;
     const size_t fixed = graph8_bwd_lists_lds(N, H, 0, 0);
     if (fixed + 64 >= limit) return 0;
     return (int64_t)((limit - fixed) / sizeof(uint16_t)) & ~(int64_t)3;
@@ -2180,7 +2478,13 @@ extern "C" int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32
     a.g_out = g; a.df1_out = df1; a.dbias_ws = dbias ? ws : nullptr; a.activation = activation;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int waves = graph8_waves(N);
-    if (lists) {
+    if (lists && LPH <= 8) {
+        // heads of at most 32 floats: one block per half row, three blocks per CU, lists read from memory (any length)
+        GATMI_REQUIRE(max_entries >= 0, GATMI_ERANGE, "dense_attn_bwd_fused: max_entries = %lld", (long long)max_entries);
+        GATMI_REQUIRE((reinterpret_cast<uintptr_t>(crow) & 7u) == 0, GATMI_EALIGN, "dense_attn_bwd_fused: crow is not 8-byte aligned");
+        a.lptr = cptr; a.lcol = crow; a.lord = cord; a.lcap = 0;
+        rc = launch_graph_bwd8_half(a, LPH, drop, st, "dense_attn_bwd_fused (prebuilt lists, half rows)");
+    } else if (lists) {
         const int64_t cap_max = gatmi_dense_lists_capacity(N, H, dp, 1);
         GATMI_REQUIRE(max_entries >= 0 && max_entries <= cap_max, GATMI_ERANGE,
                       "dense_attn_bwd_fused: a graph with %lld list entries does not fit beside its rows in LDS (at most %lld here); pass the mask and `present` instead",
