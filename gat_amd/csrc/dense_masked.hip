@@ -2456,10 +2456,12 @@ extern "C" int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32
     int rc = masked_check(B, N, H, dp, &G, &LPH, "dense_attn_bwd_fused");
     if (rc) return rc;
     if (B == 0 || N == 0) return GATMI_OK;
-    GATMI_REQUIRE(graph_fused_shape(B, N, G, LPH, H), GATMI_EUNSUPPORTED,
-                  "dense_attn_bwd_fused: B=%lld N=%d H=%d dp=%d is not a shape of the graph-resident kernels (ask gatmi_dense_attn_bwd_fused_ok)",
-                  (long long)B, N, H, dp);
     const bool lists = cptr != nullptr;
+    // the mask route keeps the graph's `present` bits and the waves' lists beside its rows; prebuilt lists need less
+    // (gatmi_dense_lists_capacity says whether a graph's rows fit at all, and how many entries beside them)
+    GATMI_REQUIRE(lists ? (graph8_shape(B, N, G, LPH) && gatmi_dense_lists_capacity(N, H, dp, 1) > 0) : graph_fused_shape(B, N, G, LPH, H), GATMI_EUNSUPPORTED,
+                  "dense_attn_bwd_fused: B=%lld N=%d H=%d dp=%d is not a shape of the graph-resident kernels (ask gatmi_dense_attn_bwd_fused_ok%s)",
+                  (long long)B, N, H, dp, lists ? " / gatmi_dense_lists_capacity" : "");
     GATMI_REQUIRE(dout && agg && pos && q && f1 && lse && Wh && f2 && df1 && dWh && df2, GATMI_EINVAL, "dense_attn_bwd_fused: null pointer");
     GATMI_REQUIRE(lists ? (crow && cord) : (bias_mat && present), GATMI_EINVAL,
                   "dense_attn_bwd_fused: give either the mask with the forward pass's `present` bits, or prebuilt lists (cptr, crow, cord)");

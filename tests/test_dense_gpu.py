@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import ref_numpy, ref_torch
-from tests.util import assert_close, layer_params
+from tests.util import assert_close, dense_dropout_masks, layer_params
 
 pytestmark = pytest.mark.gpu
 
@@ -456,6 +456,53 @@ def test_prebuilt_lists_equal_the_mask_reading_kernels_bit_for_bit(B, N, F, H, D
             continue
         assert torch.equal(a, b), "prebuilt lists vs mask: %s differs (max %g)" % (name, float((a - b).abs().max()))
     assert float(res[1][0].abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,N,F,H,D,density,drops", [(256, 132, 6, 4, 16, 0.5, (0.0, 0.0)), (256, 100, 5, 2, 32, 0.7, (0.6, 0.5)),
+                                                     (257, 320, 4, 8, 8, 0.3, (0.0, 0.0)), (256, 4, 3, 8, 8, 1.0, (0.3, 0.0))])
+def test_prebuilt_lists_longer_than_one_fetch(B, N, F, H, D, density, drops):
+    """Lists of more than 32 entries (the walk kernels fetch a row's or column's entries 32 at a time), every head
+    layout of the half-row backward kernel, the largest and the smallest graph: mask route and prebuilt lists bit for
+    bit, and the first graphs against the float64 oracle with the dropout masks replayed on the host."""
+    from gat_amd import ops
+    from gat_amd.graph import MaskLists
+    dev = torch.device("cuda:0")
+    bm = torch.tensor(_masks(B, N, density, 5 + N).astype(np.float32), device=dev)
+    ml = MaskLists(bm)
+    assert ml.fits(H, ops.padded_width(D)) and (N < 64 or ml.max_fwd > 32)
+    p = layer_params(F, H, D, seed=N + 1)
+    x = np.random.default_rng(N + 2).normal(0, 1, (B, N, F)).astype(np.float32)
+    dout = np.random.default_rng(N + 3).normal(0, 1, (B, N, H * D)).astype(np.float32)
+    res = []
+    for mask in (bm, ml):
+        tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+        xt = torch.tensor(x, device=dev, requires_grad=True)
+        cfg = ops.make_cfg(H, D, "elu", coef_drop=drops[0], in_drop=drops[1], training=True, seed=77, mask_path="lists")
+        out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], mask, cfg)
+        out.backward(torch.tensor(dout, device=dev))
+        res.append([out.detach(), xt.grad] + [tp[k].grad for k in ("W", "a1", "a2", "b1", "b2")])
+    from gat_amd import _lib
+    # the largest graphs leave the mask route no room for its bits and lists beside the rows: its backward pass then
+    # runs the row-block kernels, which add in another order
+    same_walk = bool(_lib.lib.gatmi_dense_attn_bwd_fused_ok(B, N, H, ops.padded_width(D), 1.0 - drops[0], 1.0 - drops[1]))
+    assert same_walk == (N < 320)
+    for a, b, name in zip(res[0], res[1], ("out", "dX", "dW", "da1", "da2", "db1", "db2")):
+        if same_walk or name == "out":
+            assert torch.equal(a, b), "prebuilt lists vs mask: %s differs (max %g)" % (name, float((a - b).abs().max()))
+        else:
+            assert_close(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-5, atol_scale=5e-6, what="prebuilt lists vs mask " + name)
+    g = 2
+    dp = ops.padded_width(D)
+    coef_mask, ft_mask = dense_dropout_masks(77, B, N, H, D, dp, drops[0], drops[1])
+    rp = {k: torch.tensor(v, dtype=torch.float64) for k, v in p.items()}
+    rx = torch.tensor(x[:g].astype(np.float64), requires_grad=True)
+    ref = ref_torch.layer_dense(rx, rp, bm[:g].cpu().double(), "elu", "concat",
+                                coef_mask=None if coef_mask is None else torch.tensor(coef_mask[:g]),
+                                ft_mask=None if ft_mask is None else torch.tensor(ft_mask[:g]),
+                                coef_keep=1.0 - drops[0], ft_keep=1.0 - drops[1])
+    ref.backward(torch.tensor(dout[:g].astype(np.float64)))
+    assert_close(res[1][0][:g].cpu().numpy(), ref.detach().numpy(), what="forward vs oracle")
+    assert_close(res[1][1][:g].cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what="dX vs oracle")
 
 
 def test_prebuilt_lists_refuse_masks_whose_biases_matter():
