@@ -74,7 +74,8 @@ _SIGNATURES = {
     "gatmi_dense_attn_bwd_fused_ok": (c_int, [c_int64, c_int32, c_int32, c_int32, c_float, c_float]),
     "gatmi_dense_attn_bwd_fused_ws_floats": (c_size_t, [c_int64, c_int32, c_int32]),
     "gatmi_dense_attn_bwd_fused": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, P, P, c_int32, P, P, P, P,
-                                           P, P, P, c_int64, P, P, c_float, c_float, c_float, c_uint64, P, P, P, P, P, P, P]),
+                                           P, P, P, c_int64, P, P, c_float, c_float, c_float, c_uint64, P, P, P, P, P, P, P, P, P, P, P]),
+    "gatmi_dense_attn_bwd_fused_param_grads": (c_int, [c_int32, c_int32, c_int32, c_int32]),
     "gatmi_dense_mask_bits": (c_int, [c_int64, c_int32, P, c_float, P, P]),
     "gatmi_dense_lists_count": (c_int, [c_int64, c_int32, P, P, P, P]),
     "gatmi_dense_lists_fill": (c_int, [c_int64, c_int32, P, P, P, P, P, P]),

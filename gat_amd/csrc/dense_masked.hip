@@ -1080,6 +1080,9 @@ struct MaskedBwdArgs {
     const float *dout, *out, *agg, *pos, *q, *f1, *lse, *bias;
     float *g_out, *df1_out, *dbias_ws;
     int activation;
+    // dbias_ws holds one partial row of ws_stride floats per graph: [0, 64) the bias gradient and, from
+    // dense_graph_bwd8_half_kernel when param_grads is set, [64, 128) da1, [128, 192) da2, then db1 [H], db2 [H]
+    int ws_stride, param_grads;
     // prebuilt lists (dense_graph_bwd8_kernel<.., LISTS>): column c of graph b is visited by rows
     // lcol[lptr[b*N + c] .. lptr[b*N + c + 1]) (padded to whole batches with the dummy id N); lord = columns by list length
     const int32_t *lptr;
@@ -1618,7 +1621,7 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
             if (threadIdx.x < G) {
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int i = threadIdx.x; i < (int)blockDim.x; i += G) t = f4_add(t, red[i]);
-                *reinterpret_cast<float4 *>(a.dbias_ws + b * HD + threadIdx.x * 4) = t;
+                *reinterpret_cast<float4 *>(a.dbias_ws + b * a.ws_stride + threadIdx.x * 4) = t;
             }
             __syncthreads();                              // the list area is free again
         }
@@ -1772,14 +1775,18 @@ __global__ __launch_bounds__(64 * kGraph8MaxWaves) void dense_graph_bwd8_kernel(
 // dense_graph_fwd8_lists_kernel (a lane fetches two batches of four ids, the group passes them round),
 // columns in the order of their list lengths.  Heads must not straddle the halves: H >= 2.
 // Every (column, head) adds the same terms in the same order as dense_graph_bwd8_kernel; only the partial
-// sums of the bias gradient are grouped differently.
+// sums of the bias gradient are grouped differently.  param_grads: the block also sums df1_j * Wh_j, df2_j * Wh_j
+// (da1, da2: utils/layers.py:14-15) and df1, df2 (db1, db2) over its columns while it holds them, so that no later
+// pass has to read Wh again for them.
 // ------------------------------------------------------------------------------------------
 constexpr int kHalfFloats = 32;            // floats of a row per block
 constexpr int kHalfCols = 16;              // columns per wave in the four-lane walk
-// LDS: g [N + pad][32] | stats [N + pad][3 H/2] | max(list offsets + column order, one float4 per row-slice lane and wave)
+// LDS: g [N + pad][32] | stats [N + pad][3 H/2] | max(list offsets + column order, the block sums: one float4 per
+// row-slice lane and wave for the bias gradient, eighteen floats per lane slot and wave for da1, da2, db1, db2)
+constexpr int kHalfParamSums = 18;         // per lane: da1 and da2 of its eight columns, db1, db2 of its head
 static inline size_t graph8_bwd_half_lds(int N, int H, int waves) {
-    return (size_t)(N + kGraphPadRows) * (kHalfFloats + 3 * (H / 2)) * sizeof(float) +
-           std::max(graph8_lists_head_lds(N), (size_t)waves * 8 * sizeof(float4));
+    const size_t sums = std::max((size_t)waves * 8 * sizeof(float4), (size_t)waves * 4 * kHalfParamSums * sizeof(float));
+    return (size_t)(N + kGraphPadRows) * (kHalfFloats + 3 * (H / 2)) * sizeof(float) + std::max(graph8_lists_head_lds(N), sums);
 }
 
 // Block id -> (graph, half): workgroups are dealt round-robin over the 8 XCDs, so the two halves of a graph get
@@ -1885,7 +1892,7 @@ __global__ __launch_bounds__(64 * WAVES, 12 / WAVES) void dense_graph_bwd8_half_
             if (threadIdx.x < 8) {
                 float4 t = red[threadIdx.x];
                 for (int w = 1; w < WAVES; ++w) t = f4_add(t, red[w * 8 + threadIdx.x]);
-                *reinterpret_cast<float4 *>(a.dbias_ws + b * HD + hf * HW + threadIdx.x * 4) = t;
+                *reinterpret_cast<float4 *>(a.dbias_ws + b * a.ws_stride + hf * HW + threadIdx.x * 4) = t;
             }
             __syncthreads();                              // the area is free for the list offsets
         }
@@ -1923,6 +1930,8 @@ __global__ __launch_bounds__(64 * WAVES, 12 / WAVES) void dense_graph_bwd8_half_
         o0 = off_s[jcol];
         total = j0 + c4 < N ? off_s[jcol + 1] - o0 : 0;
     };
+    float4 da1a = make_float4(0.f, 0.f, 0.f, 0.f), da1b = da1a, da2a = da1a, da2b = da1a;
+    float db1s = 0.f, db2s = 0.f;
     int j0 = wave * kHalfCols;
     int jcol = 0, o0 = 0, total = 0;
     uint4 ch = make_uint4(dummy, dummy, dummy, dummy);
@@ -1942,6 +1951,7 @@ __global__ __launch_bounds__(64 * WAVES, 12 / WAVES) void dense_graph_bwd8_half_
         const float f2v = a.f2[j * H + head];
         float4 wh0 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + oa);
         float4 wh1 = *reinterpret_cast<const float4 *>(a.Wh + j * HD + ob);
+        const float4 whu0 = wh0, whu1 = wh1;                         // the logits were formed from the undropped rows
         if (DROP) {
             if (a.feat_keep < 1.f) {
                 wh0 = drop_feat(wh0, seed, j, HD, oa, a.feat_keep);
@@ -1977,12 +1987,59 @@ __global__ __launch_bounds__(64 * WAVES, 12 / WAVES) void dense_graph_bwd8_half_
                 r1 = f4_fma(d1, *reinterpret_cast<const float4 *>(a.a1 + ob), r1);
                 r0 = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + oa), r0);
                 r1 = f4_fma(st.df2, *reinterpret_cast<const float4 *>(a.a2 + ob), r1);
+                if (a.param_grads) {
+                    da1a = f4_fma(d1, whu0, da1a);
+                    da1b = f4_fma(d1, whu1, da1b);
+                    da2a = f4_fma(st.df2, whu0, da2a);
+                    da2b = f4_fma(st.df2, whu1, da2b);
+                    db1s += d1;
+                    db2s += st.df2;
+                }
             }
             store_stream4(a.dWh + j * HD + oa, r0);
             store_stream4(a.dWh + j * HD + ob, r1);
             if (s4 % LPH8 == 0) a.df2[j * H + head] = st.df2;
         }
         jcol = jn; o0 = on; total = tn; ch = chn;
+    }
+    if (a.param_grads) {
+        // block sums in a fixed order: the sixteen columns of a wave (lanes with equal s4: two rotations inside the
+        // rows of sixteen lanes, then across the rows), then the waves through the area the list offsets leave free
+        float v[kHalfParamSums] = {da1a.x, da1a.y, da1a.z, da1a.w, da1b.x, da1b.y, da1b.z, da1b.w,
+                                   da2a.x, da2a.y, da2a.z, da2a.w, da2b.x, da2b.y, da2b.z, da2b.w, db1s, db2s};
+#pragma unroll
+        for (int k = 0; k < kHalfParamSums; ++k) {
+            float t = v[k];
+            t += dpp_f<0x124>(t, t);                      // row_ror:4
+            t += dpp_f<0x128>(t, t);                      // row_ror:8: lanes i, i+4, i+8, i+12 of the row
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            v[k] = t;
+        }
+        __syncthreads();                                  // every wave has finished its walk: offsets and order are dead
+        float *red = reinterpret_cast<float *>(area);     // [WAVES][4][18]
+        if (lane < 4) {
+#pragma unroll
+            for (int k = 0; k < kHalfParamSums; ++k) red[(wave * 4 + lane) * kHalfParamSums + k] = v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {                            // lane slot s4 = threadIdx.x: pa, pb, head as computed above
+#pragma unroll
+            for (int k = 0; k < kHalfParamSums; ++k) {
+                float t = red[threadIdx.x * kHalfParamSums + k];
+                for (int w = 1; w < WAVES; ++w) t += red[(w * 4 + threadIdx.x) * kHalfParamSums + k];
+                v[k] = t;
+            }
+            float *row = a.dbias_ws + b * a.ws_stride;
+            *reinterpret_cast<float4 *>(row + HD + oa) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4 *>(row + HD + ob) = make_float4(v[4], v[5], v[6], v[7]);
+            *reinterpret_cast<float4 *>(row + 2 * HD + oa) = make_float4(v[8], v[9], v[10], v[11]);
+            *reinterpret_cast<float4 *>(row + 2 * HD + ob) = make_float4(v[12], v[13], v[14], v[15]);
+            if (s4 % LPH8 == 0) {
+                row[3 * HD + head] = v[16];
+                row[3 * HD + H + head] = v[17];
+            }
+        }
     }
 }
 
@@ -1992,6 +2049,19 @@ __global__ void graph_dbias_sum_kernel(const float *ws, int rows, int width, flo
     const bool ok = c < width;
     const float t = block_column_sum(rows, [&](int r) { return ok ? ws[(int64_t)r * width + c] : 0.f; });
     if (ok && threadIdx.y == 0) out[c] = t;
+}
+
+// the same over rows of [dbias 64 | da1 64 | da2 64 | db1 H | db2 H]: each column's total goes to its own array
+__global__ void graph_param_sum_kernel(const float *ws, int rows, int width, int H, float *dbias, float *da1, float *da2, float *db1, float *db2) {
+    const int c = blockIdx.x * kSumCols + threadIdx.x;
+    const bool ok = c < width;
+    const float t = block_column_sum(rows, [&](int r) { return ok ? ws[(int64_t)r * width + c] : 0.f; });
+    if (!ok || threadIdx.y != 0) return;
+    if (c < 64) { if (dbias) dbias[c] = t; }
+    else if (c < 128) da1[c - 64] = t;
+    else if (c < 192) da2[c - 128] = t;
+    else if (c < 192 + H) db1[c - 192] = t;
+    else db2[c - 192 - H] = t;
 }
 
 // first stage for many graphs: block (bx, by) sums rows [by * per, (by + 1) * per) into out[by][c]
@@ -2200,6 +2270,8 @@ static int masked_check(int64_t B, int32_t N, int32_t H, int32_t dp, int *G, int
     return GATMI_OK;
 }
 
+extern "C" int64_t gatmi_dense_lists_capacity(int32_t N, int32_t H, int32_t dp, int32_t backward);
+
 extern "C" size_t gatmi_dense_mask_words(int32_t N) { return N < 0 ? 0 : (size_t)(N + 31) / 32 + 1; }
 
 extern "C" int gatmi_dense_attn_fwd_masked(int64_t B, int32_t N, int32_t H, int32_t dp,
@@ -2347,8 +2419,14 @@ extern "C" int gatmi_dense_attn_bwd_fused_ok(int64_t B, int32_t N, int32_t H, in
 }
 
 extern "C" size_t gatmi_dense_attn_bwd_fused_ws_floats(int64_t B, int32_t H, int32_t dp) {
-    // one partial row per graph, then one per kDbiasStageRows graphs
-    return B <= 0 ? 0 : (size_t)(B + (B + kDbiasStageRows - 1) / kDbiasStageRows) * (size_t)H * dp;
+    // one partial row per graph, then one per kDbiasStageRows graphs; a row holds dbias and, when the kernel also
+    // sums the attention parameters' gradients, da1, da2, db1, db2
+    return B <= 0 ? 0 : (size_t)(B + (B + kDbiasStageRows - 1) / kDbiasStageRows) * (size_t)(3 * H * dp + 2 * H);
+}
+
+extern "C" int gatmi_dense_attn_bwd_fused_param_grads(int32_t N, int32_t H, int32_t dp, int32_t lists) {
+    // the half-row kernel over prebuilt lists: rows of 64 floats in at least two heads
+    return lists && H >= 2 && gatmi_dense_lists_capacity(N, H, dp, 1) > 0 ? 1 : 0;
 }
 
 extern "C" int64_t gatmi_dense_lists_capacity(int32_t N, int32_t H, int32_t dp, int32_t backward) {
@@ -2450,7 +2528,8 @@ extern "C" int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32
                                           const int32_t *cptr, const uint16_t *crow, const uint16_t *cord, int64_t max_entries,
                                           const float *a1, const float *a2, float slope,
                                           float coef_keep, float feat_keep, uint64_t seed,
-                                          float *g, float *df1, float *dbias, float *ws,
+                                          float *g, float *df1, float *dbias,
+                                          float *da1, float *da2, float *db1, float *db2, float *ws,
                                           float *dWh, float *df2, void *stream) {
     int G, LPH;
     int rc = masked_check(B, N, H, dp, &G, &LPH, "dense_attn_bwd_fused");
@@ -2466,7 +2545,11 @@ extern "C" int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32
     GATMI_REQUIRE(lists ? (crow && cord) : (bias_mat && present), GATMI_EINVAL,
                   "dense_attn_bwd_fused: give either the mask with the forward pass's `present` bits, or prebuilt lists (cptr, crow, cord)");
     GATMI_REQUIRE((a1 == nullptr) == (a2 == nullptr), GATMI_EINVAL, "dense_attn_bwd_fused: a1 and a2 go together");
-    GATMI_REQUIRE(!dbias || ws, GATMI_EINVAL, "dense_attn_bwd_fused: dbias needs ws (gatmi_dense_attn_bwd_fused_ws_floats)");
+    const bool params = da1 || da2 || db1 || db2;
+    GATMI_REQUIRE(!params || (da1 && da2 && db1 && db2 && a1), GATMI_EINVAL, "dense_attn_bwd_fused: da1, da2, db1, db2 go together and need a1, a2");
+    GATMI_REQUIRE(!params || gatmi_dense_attn_bwd_fused_param_grads(N, H, dp, lists ? 1 : 0), GATMI_EUNSUPPORTED,
+                  "dense_attn_bwd_fused: this route does not sum da1, da2, db1, db2 (ask gatmi_dense_attn_bwd_fused_param_grads); pass NULL and use gatmi_proj_bwd_params");
+    GATMI_REQUIRE(!(dbias || params) || ws, GATMI_EINVAL, "dense_attn_bwd_fused: dbias, da1.. need ws (gatmi_dense_attn_bwd_fused_ws_floats)");
     GATMI_REQUIRE(act_known(activation), GATMI_EUNSUPPORTED, "dense_attn_bwd_fused: activation %d", activation);
     GATMI_REQUIRE(coef_keep > 0.f && coef_keep <= 1.f && feat_keep > 0.f && feat_keep <= 1.f, GATMI_EINVAL, "dense_attn_bwd_fused: keep probabilities must be in (0,1]");
     const bool drop = coef_keep < 1.f || feat_keep < 1.f;
@@ -2477,7 +2560,10 @@ extern "C" int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32
     a.dWh = dWh; a.df2 = df2; a.slope = slope; a.coef_keep = coef_keep; a.feat_keep = feat_keep; a.seed = seed;
     a.seed_step = drop ? dropout_step_source() : nullptr;
     a.dout = dout; a.out = out; a.agg = agg; a.pos = pos; a.q = q; a.f1 = f1; a.lse = lse; a.bias = out ? nullptr : bias;
-    a.g_out = g; a.df1_out = df1; a.dbias_ws = dbias ? ws : nullptr; a.activation = activation;
+    a.g_out = g; a.df1_out = df1; a.dbias_ws = (dbias || params) ? ws : nullptr; a.activation = activation;
+    const int hd = H * dp;
+    a.param_grads = params ? 1 : 0;
+    a.ws_stride = params ? 3 * hd + 2 * H : hd;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int waves = graph8_waves(N);
     if (lists && LPH <= 8) {
@@ -2500,18 +2586,21 @@ extern "C" int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32
         rc = launch_graph_bwd8_fused<false>(a, LPH, drop, graph8_bwd_lds(N, H, lc, waves), lc, st, "dense_attn_bwd_fused");
     }
     if (rc) return rc;
-    if (dbias) {
-        const int hd = H * dp;
+    if (dbias || params) {
+        const int width = a.ws_stride;
         const float *rows = ws;
         int n_rows = (int)B;
         if (B > 4 * kDbiasStageRows) {
             n_rows = (int)((B + kDbiasStageRows - 1) / kDbiasStageRows);
-            float *stage = ws + (size_t)B * hd;
-            hipLaunchKernelGGL(graph_dbias_stage_kernel, dim3((hd + kSumCols - 1) / kSumCols, n_rows), dim3(kSumCols, kSumRows), 0, st, ws, (int)B, hd, stage);
+            float *stage = ws + (size_t)B * width;
+            hipLaunchKernelGGL(graph_dbias_stage_kernel, dim3((width + kSumCols - 1) / kSumCols, n_rows), dim3(kSumCols, kSumRows), 0, st, ws, (int)B, width, stage);
             GATMI_LAUNCH_CHECK("dense_attn_bwd_fused dbias stage");
             rows = stage;
         }
-        hipLaunchKernelGGL(graph_dbias_sum_kernel, dim3((hd + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, rows, n_rows, hd, dbias);
+        if (params)
+            hipLaunchKernelGGL(graph_param_sum_kernel, dim3((width + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, rows, n_rows, width, H, dbias, da1, da2, db1, db2);
+        else
+            hipLaunchKernelGGL(graph_dbias_sum_kernel, dim3((width + kSumCols - 1) / kSumCols), dim3(kSumCols, kSumRows), 0, st, rows, n_rows, width, dbias);
         GATMI_LAUNCH_CHECK("dense_attn_bwd_fused dbias");
     }
     return GATMI_OK;

@@ -123,16 +123,21 @@ def _project(x2d, W, a1, a2, b1, b2, cfg, W_res=None, b_res=None, Wh16_out=None)
     return Wp, a1p, a2p, Wrp, Wh, f1, f2, res
 
 
-def _project_backward(x2d, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, need_dx):
-    """Backward of _project: dW, da1, da2, db1, db2 (+ dW_res, db_res, dX)."""
+def _project_backward(x2d, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, need_dx, attn_grads=None):
+    """Backward of _project: dW, da1, da2, db1, db2 (+ dW_res, db_res, dX).  attn_grads: (da1, da2, db1, db2) when
+    the attention kernel has already summed them (padded [hd], [hd], [H], [H]); Wh is then not read again."""
     n, F = x2d.shape
     H, D, dp = cfg.H, cfg.D, cfg.dp
     hd = H * dp
     st = _lib.current_stream()
     ws = _new((_lib.lib.gatmi_proj_bwd_ws_floats(F, H, dp),), x2d)
     dW = _new((F, hd), x2d)
-    da1, da2 = _new((hd,), x2d), _new((hd,), x2d)
-    db1, db2 = _new((H,), x2d), _new((H,), x2d)
+    if attn_grads is not None:
+        da1, da2, db1, db2 = attn_grads
+        Wh = df1 = df2 = None
+    else:
+        da1, da2 = _new((hd,), x2d), _new((hd,), x2d)
+        db1, db2 = _new((H,), x2d), _new((H,), x2d)
 
     def unpad(t, lead):
         return t.reshape(*lead, H, dp)[..., :D]
@@ -141,8 +146,12 @@ def _project_backward(x2d, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, need_dx):
                   ptr(df1), ptr(df2), H, dp, ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(ws), st)
         return None, unpad(dW, (F,)), unpad(da1, ()), unpad(da2, ()), db1, db2, None
     xk, sd = cfg.x_keep, cfg.seed
-    _lib.call("gatmi_proj_bwd_params", ptr(x2d), n, F, x2d.stride(0), ptr(dWh), ptr(Wh), ptr(df1), ptr(df2), H, dp,
-              ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(ws), xk, sd, st)
+    if attn_grads is not None:
+        _lib.call("gatmi_proj_bwd_params", ptr(x2d), n, F, x2d.stride(0), ptr(dWh), None, None, None, H, dp,
+                  ptr(dW), None, None, None, None, ptr(ws), xk, sd, st)
+    else:
+        _lib.call("gatmi_proj_bwd_params", ptr(x2d), n, F, x2d.stride(0), ptr(dWh), ptr(Wh), ptr(df1), ptr(df2), H, dp,
+                  ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(ws), xk, sd, st)
     dWr = None
     if Wrp is not None:
         dWr = _new((F, hd), x2d)
@@ -411,11 +420,16 @@ class DenseGATLayerFn(torch.autograd.Function):
             g = _new((n, hd), x2) if ctx.has_res else None          # only the residual branch reads g afterwards
             ws = _new((_lib.lib.gatmi_dense_attn_bwd_fused_ws_floats(B, H, dp),), x2)
             lists = (None, None, None, 0) if ml is None else (ptr(ml.cptr), ptr(ml.crow), ptr(ml.cord), ml.max_bwd)
+            # over prebuilt lists the kernel also sums da1, da2, db1, db2 while it holds the graph's Wh rows and df
+            attn_grads = None
+            if _lib.lib.gatmi_dense_attn_bwd_fused_param_grads(N, H, dp, 0 if ml is None else 1):
+                attn_grads = (_new((hd,), x2), _new((hd,), x2), _new((H,), x2), _new((H,), x2))
             _lib.call("gatmi_dense_attn_bwd_fused", B, N, H, dp, ptr(dout), ptr(out) if ctx.has_res else None, ptr(agg), ptr(pos),
                       ptr(q), ptr(f1), ptr(lse), ptr(biasp), _ACT[cfg.activation], ptr(Wh), ptr(f2), ptr(bias_mat), ptr(ctx.present),
                       *lists, ptr(a1p), ptr(a2p), cfg.slope, cfg.coef_keep, cfg.feat_keep, cfg.seed,
-                      ptr(g), ptr(df1), ptr(dbias), ptr(ws), ptr(dWh), ptr(df2), st)
-            dx, dW, da1, da2, db1, db2, dWr = _project_backward(x2, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0])
+                      ptr(g), ptr(df1), ptr(dbias), *((None,) * 4 if attn_grads is None else [ptr(t) for t in attn_grads]),
+                      ptr(ws), ptr(dWh), ptr(df2), st)
+            dx, dW, da1, da2, db1, db2, dWr = _project_backward(x2, Wp, Wrp, Wh, dWh, df1, df2, g, cfg, ctx.needs_input_grad[0], attn_grads)
             if dx is not None:
                 dx = dx.reshape(B, N, -1)
             db = dbias.reshape(H, dp)[:, :D] if ctx.has_bias else None

@@ -389,10 +389,17 @@ int gatmi_dense_attn_bwd_masked(int64_t B, int32_t N, int32_t H, int32_t dp,
  * a graph forms g, the row statistics and df1 of its nodes while it stages them, so they make no round trip
  * through memory and one launch per step goes away.  Arguments as in those two calls; g may be NULL (it is only
  * needed by a residual branch), dbias may be NULL, ws: gatmi_dense_attn_bwd_fused_ws_floats(B, H, dp) floats when
- * dbias is given.  The structure of the mask comes EITHER from bias_mat + the forward pass's `present` bits
+ * dbias or da1.. are given.  The structure of the mask comes EITHER from bias_mat + the forward pass's `present` bits
  * (cptr = crow = cord = NULL) OR from prebuilt lists (cptr, crow, cord, max_entries from the calls below;
- * bias_mat and present may then be NULL).  Other shapes: GATMI_EUNSUPPORTED (use the two calls). */
+ * bias_mat and present may then be NULL; the shape is then covered whenever gatmi_dense_lists_capacity(N, H, dp, 1)
+ * is not 0).  Other shapes: GATMI_EUNSUPPORTED (use the two calls).
+ * da1, da2 [H*dp], db1, db2 [H] (all four or none; need a1, a2 and ws): the gradients of the attention vectors and
+ * their scalar biases (utils/layers.py:14-15), da1 = sum_j df1_j Wh_j, da2 = sum_j df2_j Wh_j, db = sum_j df_j, summed
+ * by the block that holds the graph's Wh rows and df anyway, so that gatmi_proj_bwd_params need not read Wh again
+ * (call it with Wh = df1 = df2 = da1.. = NULL for dW alone).  Only where gatmi_dense_attn_bwd_fused_param_grads says 1
+ * (prebuilt lists, at least two heads); elsewhere pass NULL. */
 int gatmi_dense_attn_bwd_fused_ok(int64_t B, int32_t N, int32_t H, int32_t dp, float coef_keep, float feat_keep);
+int gatmi_dense_attn_bwd_fused_param_grads(int32_t N, int32_t H, int32_t dp, int32_t lists);
 size_t gatmi_dense_attn_bwd_fused_ws_floats(int64_t B, int32_t H, int32_t dp);
 int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32_t dp,
                                const float *dout, const float *out, const float *agg, const float *pos,
@@ -401,7 +408,8 @@ int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32_t dp,
                                const int32_t *cptr, const uint16_t *crow, const uint16_t *cord, int64_t max_entries,
                                const float *a1, const float *a2, float slope,
                                float coef_keep, float feat_keep, uint64_t seed,
-                               float *g, float *df1, float *dbias, float *ws,
+                               float *g, float *df1, float *dbias,
+                               float *da1, float *da2, float *db1, float *db2, float *ws,
                                float *dWh, float *df2, void *stream);
 
 /* A mask that stays the same step after step (the reference feeds one bias_mat every epoch,
