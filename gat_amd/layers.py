@@ -75,15 +75,14 @@ class _MaskGraphs:
         if e[2] is None:             # second sighting: decide
             if torch.cuda.is_current_stream_capturing():
                 return None
-            d = ops._mask_density(t)
+            f = ops._mask_facts(t)
             e[2] = False
-            if d is not None and d <= ops.MASK_LIST_DENSITY:
+            B, N = t.shape[:2]
+            small = ops.graph_resident_batch(B, N) and t.dtype == torch.float32
+            # many small graphs: prebuilt lists beat the matrix-core kernels at (nearly) every density of a hard mask
+            if f is not None and not (small and f[1]) and f[0] <= (ops.GRAPH_LIST_DENSITY if small else ops.MASK_LIST_DENSITY):
                 try:
-                    B, N = t.shape[:2]
-                    if B >= 256 and N % 4 == 0 and 4 <= N <= 320 and t.dtype == torch.float32:
-                        e[2] = MaskLists(t)
-                    else:
-                        e[2] = CSRGraph.from_bias_mat(t)
+                    e[2] = MaskLists(t) if small else CSRGraph.from_bias_mat(t)
                 except ValueError:   # biases differ inside a row: the dense kernels add them
                     pass
         g = e[2] or None

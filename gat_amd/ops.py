@@ -277,12 +277,24 @@ class SparseGATLayerFn(torch.autograd.Function):
         return dx, dW, da1, da2, db1, db2, db, dWr, dbr, None, None
 
 
-MASK_LIST_DENSITY = 0.35      # the list kernels win below about a third of the entries contributing
+MASK_LIST_DENSITY = 0.35      # the list kernels win below about a third of the entries contributing ...
+# ... except for batches of many small graphs with rows of 64 floats (the graph-resident list kernels): at 4096 graphs
+# of 264 nodes, 8 heads of 8, they take 2.4 / 3.0 / 3.7 / 5.3 ms at densities 0.2 / 0.35 / 0.5 / 1.0 against 5.3 ms of
+# the matrix-core kernels at any density (hard masks; fp32 matrix instructions share the vector ALUs' multipliers, and at
+# heads of 8 floats nine of a tile's sixteen columns do work).  Soft masks, whose walk fetches a bias per entry, keep
+# the lower bound.
+GRAPH_LIST_DENSITY = 0.9
 _density_cache = {}
 
 
-def _mask_density(bias_mat):
-    """Fraction of mask entries that can contribute (within 1e6 of their row's maximum), estimated on
+def graph_resident_batch(B, N):
+    """Batch shapes the graph-resident kernels take: at least 256 graphs of 4..320 nodes, a multiple of 4."""
+    return B >= 256 and N % 4 == 0 and 4 <= N <= 320
+
+
+def _mask_facts(bias_mat):
+    """(density, soft): the fraction of mask entries that can contribute (within 1e6 of their row's maximum) and
+    whether some of them differ from that maximum (the bias then matters to the softmax), estimated on
     the first graphs of the batch and remembered per tensor version.  None while a HIP graph is being
     captured and nothing is remembered (the estimate needs a device-to-host copy).  The memo is keyed
     on address, shape and version counter; a different mask that reuses a freed tensor's address can
@@ -293,11 +305,28 @@ def _mask_density(bias_mat):
         if torch.cuda.is_current_stream_capturing():
             return None
         sample = bias_mat[:max(1, min(bias_mat.shape[0], (1 << 22) // max(1, bias_mat.shape[1] * bias_mat.shape[2])))]
-        d = float((sample > sample.amax(-1, keepdim=True) - 1.0e6).float().mean())
+        top = sample.amax(-1, keepdim=True)
+        seen = sample > top - 1.0e6
+        facts = torch.stack((seen.float().mean(), (seen & (sample != top)).any().float())).tolist()
+        d = (float(facts[0]), facts[1] > 0)
         if len(_density_cache) > 64:
             _density_cache.clear()
         _density_cache[key] = d
     return d
+
+
+def _mask_density(bias_mat):
+    f = _mask_facts(bias_mat)
+    return None if f is None else f[0]
+
+
+def mask_list_density_limit(cfg, bias_mat):
+    """Density up to which the list kernels are the faster family for this mask and layer shape."""
+    f = _mask_facts(bias_mat)
+    B, N = bias_mat.shape[:2]
+    if f is not None and not f[1] and cfg.H * cfg.dp == 64 and cfg.dp >= 8 and graph_resident_batch(B, N):
+        return GRAPH_LIST_DENSITY
+    return MASK_LIST_DENSITY
 
 
 # (heads, padded width) pairs the matrix-core kernels are built for (GATMI_DENSE_SHAPES in dense_attn.hip)
@@ -317,7 +346,7 @@ def _use_mask_lists(cfg, bias_mat):
     if (cfg.H, cfg.dp) not in _MFMA_SHAPES:
         return True
     d = _mask_density(bias_mat)
-    return d is not None and d <= MASK_LIST_DENSITY
+    return d is not None and d <= mask_list_density_limit(cfg, bias_mat)
 
 
 def _widen_for_lists(cfg, bias_mat):

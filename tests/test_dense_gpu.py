@@ -131,6 +131,18 @@ def test_rows_masked_everywhere_and_automatic_choice():
     dense_mask = torch.zeros(B, N, N, device=dev)
     assert ops._mask_density(dense_mask) == 1.0
     assert not ops._use_mask_lists(ops.make_cfg(H, D), dense_mask)
+    # a batch of many small graphs (the graph-resident list kernels): lists at any density of a hard mask, not for
+    # dense soft masks, not for rows that are not 64 floats
+    many = torch.zeros(256, N, N, device=dev)
+    many[:, :, ::2] = -1e9
+    many[:, torch.arange(N), torch.arange(N)] = 0.0
+    assert ops._mask_facts(many) == (pytest.approx(0.5, abs=0.02), False)
+    assert ops._use_mask_lists(ops.make_cfg(H, D), many)
+    assert ops._use_mask_lists(ops.make_cfg(H, D), torch.zeros(256, N, N, device=dev)) is False     # density 1.0 > 0.9
+    assert not ops._use_mask_lists(ops.make_cfg(4, 8), many)
+    soft = many.clone()
+    soft[:, 1, 1] = -0.5
+    assert ops._mask_facts(soft)[1] and not ops._use_mask_lists(ops.make_cfg(H, D), soft)
 
 
 @pytest.mark.parametrize("path", ["dense", "lists"])
