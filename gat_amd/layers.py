@@ -80,7 +80,8 @@ class _MaskGraphs:
             B, N = t.shape[:2]
             small = ops.graph_resident_batch(B, N) and t.dtype == torch.float32
             # many small graphs: prebuilt lists beat the matrix-core kernels at (nearly) every density of a hard mask
-            if f is not None and not (small and f[1]) and f[0] <= (ops.GRAPH_LIST_DENSITY if small else ops.MASK_LIST_DENSITY):
+            # (4096 x 264, a full mask: 4.7 ms on prebuilt lists, 5.3 ms on the matrix cores)
+            if f is not None and not (small and f[1]) and (small or f[0] <= ops.MASK_LIST_DENSITY):
                 try:
                     e[2] = MaskLists(t) if small else CSRGraph.from_bias_mat(t)
                 except ValueError:   # biases differ inside a row: the dense kernels add them
