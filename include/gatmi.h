@@ -432,8 +432,11 @@ int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32_t dp,
  *                             list entries one graph holds (forward: rows; backward: columns)
  *   gatmi_dense_lists_fill    lcol, crow: the lists, padded with the id N, in the order in which the compacting
  *                             kernels build theirs (results are bit-identical to the mask-reading kernels)
- *   gatmi_dense_lists_capacity  list entries of one graph that fit beside its rows in LDS for this shape
- *                             (backward != 0: for gatmi_dense_attn_bwd_fused); 0: shape not covered
+ *   gatmi_dense_lists_capacity  list entries one graph may hold for this shape (backward != 0: for
+ *                             gatmi_dense_attn_bwd_fused); 0: shape not covered.  The forward kernel and, with at
+ *                             least two heads, the backward kernel read their lists from memory, so every list fits
+ *                             ((N + 4) * N); one head of 64 floats in the backward pass: what fits beside the graph's
+ *                             rows in LDS
  *   gatmi_dense_attn_fwd_lists  gatmi_dense_attn_fwd_masked on the lists; GATMI_ERANGE when max_entries exceeds
  *                             the capacity.  A caller that understates max_entries gets wrong rows for the graphs
  *                             that exceed it, never an out-of-bounds access.
