@@ -368,7 +368,9 @@ int gatmi_dense_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t dp,
  * NULL when agg..q are NULL) receives one bit per visited entry plus a flag word per row; the
  * backward kernel walks those bits instead of reading the fp32 mask again (it fetches bias values
  * only in rows whose visited entries are not all zero).  Faster than the dense kernels when about a
- * third or fewer of the entries of a row contribute; H*dp >= 32, N <= 32767. */
+ * third or fewer of the entries of a row contribute — and, for batches of at least 256 graphs of 4..320
+ * nodes (N % 4 == 0) with rows of 64 floats in heads of >= 8, whose graphs the kernels keep resident in
+ * LDS, at every density of a hard mask (equal on a full one); H*dp >= 32, N <= 32767. */
 size_t gatmi_dense_mask_words(int32_t N);
 int gatmi_dense_attn_fwd_masked(int64_t B, int32_t N, int32_t H, int32_t dp,
                                 const float *Wh, const float *f1, const float *f2, const float *bias_mat,
