@@ -1784,9 +1784,13 @@ constexpr int kHalfCols = 16;              // columns per wave in the four-lane 
 // LDS: g [N + pad][32] | stats [N + pad][3 H/2] | max(list offsets + column order, the block sums: one float4 per
 // row-slice lane and wave for the bias gradient, eighteen floats per lane slot and wave for da1, da2, db1, db2)
 constexpr int kHalfParamSums = 18;         // per lane: da1 and da2 of its eight columns, db1, db2 of its head
+// bytes of the rows' part, rounded up to the 16 bytes the float4 sums behind it need (any N: prebuilt lists do not ask for N % 4 == 0)
+__host__ __device__ inline size_t graph8_bwd_half_rows(int N, int heads_of_half) {
+    return ((size_t)(N + kGraphPadRows) * (kHalfFloats + 3 * heads_of_half) * sizeof(float) + 15) & ~(size_t)15;
+}
 static inline size_t graph8_bwd_half_lds(int N, int H, int waves) {
     const size_t sums = std::max((size_t)waves * 8 * sizeof(float4), (size_t)waves * 4 * kHalfParamSums * sizeof(float));
-    return (size_t)(N + kGraphPadRows) * (kHalfFloats + 3 * (H / 2)) * sizeof(float) + std::max(graph8_lists_head_lds(N), sums);
+    return graph8_bwd_half_rows(N, H / 2) + std::max(graph8_lists_head_lds(N), sums);
 }
 
 // Block id -> (graph, half): workgroups are dealt round-robin over the 8 XCDs, so the two halves of a graph get
@@ -1814,7 +1818,7 @@ __global__ __launch_bounds__(64 * WAVES, 12 / WAVES) void dense_graph_bwd8_half_
     if (b >= a.B) return;
     float *gs = reinterpret_cast<float *>(graph_smem);                        // [NP][HW]
     float *ss = gs + NP * HW;                                                 // [NP][SS]
-    unsigned char *area = reinterpret_cast<unsigned char *>(ss + NP * SS);
+    unsigned char *area = graph_smem + graph8_bwd_half_rows(N, HB);
     int *off_s = reinterpret_cast<int *>(area);
     uint16_t *ord_s = reinterpret_cast<uint16_t *>(off_s + ((N + 2) & ~1));
     const uint64_t seed = DROP ? seed_now(a) : 0;
@@ -2168,8 +2172,10 @@ using namespace gatmi;
 
 // shapes of the graph-resident kernels with the eight-lane walk: rows of 64 floats in heads of >= 8, graphs of
 // 4 .. 320 nodes (a multiple of 4), one block per graph and at least one block per CU
-static bool graph8_shape(int64_t B, int32_t N, int G, int LPH) {
-    return G == 16 && LPH >= 2 && (N & 3) == 0 && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && B <= 0x7fffffff;
+// (N a multiple of 4 is what the mask-reading kernels need for their 16-byte mask loads; kernels that walk prebuilt lists
+// from memory take any N: lists_only)
+static bool graph8_shape(int64_t B, int32_t N, int G, int LPH, bool lists_only = false) {
+    return G == 16 && LPH >= 2 && (lists_only || (N & 3) == 0) && N >= 4 && N <= kGraphMaxN && B >= kGraphMinBatch && B <= 0x7fffffff;
 }
 
 static int launch_graph_fwd8(const MaskedFwdArgs &a, int LPH, bool save, bool drop, size_t lds, int lc, hipStream_t st, const char *name) {
@@ -2430,12 +2436,13 @@ extern "C" int gatmi_dense_attn_bwd_fused_param_grads(int32_t N, int32_t H, int3
 }
 
 extern "C" int64_t gatmi_dense_lists_capacity(int32_t N, int32_t H, int32_t dp, int32_t backward) {
-    if (H <= 0 || dp < 8 || !is_pow2(dp) || !is_pow2(H) || H * dp != 64 || N < 4 || (N & 3) || N > kGraphMaxN) return 0;
+    if (H <= 0 || dp < 8 || !is_pow2(dp) || !is_pow2(H) || H * dp != 64 || N < 4 || N > kGraphMaxN) return 0;
     const size_t limit = graph_lds_limit();
     if (!backward)                                       // the forward kernel reads its lists from memory: any length, if the rows fit
         return graph8_fwd_walk_lds(N, H) <= limit ? (int64_t)(N + kGraphBatch) * N : 0;
     if (H >= 2)                                          // half-row blocks read their lists from memory as well
         return graph8_bwd_half_lds(N, H, kHalfWaves) <= limit ? (int64_t)(N + kGraphBatch) * N : 0;
+    if (N & 3) return 0;                                 // one head of 64 floats: the whole-row kernel stages the lists (8-byte aligned areas)
     const size_t fixed = graph8_bwd_lists_lds(N, H, 0, 0);
     if (fixed + 64 >= limit) return 0;
     return (int64_t)((limit - fixed) / sizeof(uint16_t)) & ~(int64_t)3;
@@ -2454,8 +2461,8 @@ extern "C" int gatmi_dense_mask_bits(int64_t B, int32_t N, const float *bias_mat
 
 static int lists_check(int64_t B, int32_t N, const char *name) {
     GATMI_REQUIRE(B >= 0 && N >= 0, GATMI_EINVAL, "%s: negative size", name);
-    GATMI_REQUIRE(N >= 4 && (N & 3) == 0 && N <= kGraphMaxN, GATMI_EUNSUPPORTED,
-                  "%s: prebuilt lists are for the graph-resident kernels (graphs of 4 .. %d nodes, a multiple of 4), N = %d", name, kGraphMaxN, N);
+    GATMI_REQUIRE(N >= 4 && N <= kGraphMaxN, GATMI_EUNSUPPORTED,
+                  "%s: prebuilt lists are for the graph-resident kernels (graphs of 4 .. %d nodes), N = %d", name, kGraphMaxN, N);
     GATMI_REQUIRE(B <= 0x7fffffff && B * (int64_t)N < 0x7fffffff, GATMI_ERANGE, "%s: too large for one launch", name);
     return GATMI_OK;
 }
@@ -2496,7 +2503,7 @@ extern "C" int gatmi_dense_attn_fwd_lists(int64_t B, int32_t N, int32_t H, int32
     if (rc) return rc;
     if (B == 0 || N == 0) return GATMI_OK;
     GATMI_REQUIRE(Wh && f1 && f2 && lptr && lcol && lord && out, GATMI_EINVAL, "dense_attn_fwd_lists: null pointer");
-    GATMI_REQUIRE(graph8_shape(B, N, G, LPH), GATMI_EUNSUPPORTED,
+    GATMI_REQUIRE(graph8_shape(B, N, G, LPH, true), GATMI_EUNSUPPORTED,
                   "dense_attn_fwd_lists: B=%lld N=%d H=%d dp=%d is not a shape of the graph-resident kernels (rows of 64 floats in heads of >= 8, "
                   "graphs of 4 .. %d nodes, at least %lld graphs)", (long long)B, N, H, dp, kGraphMaxN, (long long)kGraphMinBatch);
     const int64_t cap_max = gatmi_dense_lists_capacity(N, H, dp, 0);
@@ -2538,7 +2545,7 @@ extern "C" int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32
     const bool lists = cptr != nullptr;
     // the mask route keeps the graph's `present` bits and the waves' lists beside its rows; prebuilt lists need less
     // (gatmi_dense_lists_capacity says whether a graph's rows fit at all, and how many entries beside them)
-    GATMI_REQUIRE(lists ? (graph8_shape(B, N, G, LPH) && gatmi_dense_lists_capacity(N, H, dp, 1) > 0) : graph_fused_shape(B, N, G, LPH, H), GATMI_EUNSUPPORTED,
+    GATMI_REQUIRE(lists ? (graph8_shape(B, N, G, LPH, true) && gatmi_dense_lists_capacity(N, H, dp, 1) > 0) : graph_fused_shape(B, N, G, LPH, H), GATMI_EUNSUPPORTED,
                   "dense_attn_bwd_fused: B=%lld N=%d H=%d dp=%d is not a shape of the graph-resident kernels (ask gatmi_dense_attn_bwd_fused_ok%s)",
                   (long long)B, N, H, dp, lists ? " / gatmi_dense_lists_capacity" : "");
     GATMI_REQUIRE(dout && agg && pos && q && f1 && lse && Wh && f2 && df1 && dWh && df2, GATMI_EINVAL, "dense_attn_bwd_fused: null pointer");

@@ -215,8 +215,8 @@ class MaskLists:
         bias_mat = bias_mat.contiguous()
         B, N, _ = bias_mat.shape
         dev = bias_mat.device
-        if B * N >= 2 ** 31 - 1 or N % 4 or not (4 <= N <= 320):
-            raise ValueError("MaskLists: graphs of 4..320 nodes (a multiple of 4) are covered, got N = %d" % N)
+        if B * N >= 2 ** 31 - 1 or not (4 <= N <= 320):
+            raise ValueError("MaskLists: graphs of 4..320 nodes are covered, got N = %d" % N)
         st = _lib.current_stream()
         W = _lib.lib.gatmi_dense_mask_words(N)
         bits = torch.empty((B * N, W), dtype=torch.int32, device=dev)

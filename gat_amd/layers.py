@@ -70,15 +70,20 @@ class _MaskGraphs:
             if len(self._entries) > 16:
                 self._entries = {k: v for k, v in self._entries.items() if v[0]() is not None}
             key = id(t)
-            self._entries[key] = [weakref.ref(t, lambda _r, k=key: self._drop(k, _r)), t._version, None]
-            return None
-        if e[2] is None:             # second sighting: decide
+            e = self._entries[key] = [weakref.ref(t, lambda _r, k=key: self._drop(k, _r)), t._version, None]
+            # A batch of small graphs whose size is not a multiple of 4 (the reference's 246- and 90-node atlases) has no
+            # mask-reading graph-resident kernels to fall back on: building the lists costs less than ONE step on the
+            # row-block kernels saves (4096 x 246: 1.6 ms once, then 1.2 instead of 3.2 ms per step), so decide at once.
+            B, N = t.shape[:2]
+            if not (ops.prebuilt_lists_batch(B, N) and not ops.graph_resident_batch(B, N) and t.dtype == torch.float32):
+                return None
+        if e[2] is None:             # second sighting (or the first, see above): decide
             if torch.cuda.is_current_stream_capturing():
                 return None
             f = ops._mask_facts(t)
             e[2] = False
             B, N = t.shape[:2]
-            small = ops.graph_resident_batch(B, N) and t.dtype == torch.float32
+            small = ops.prebuilt_lists_batch(B, N) and t.dtype == torch.float32
             # many small graphs: prebuilt lists beat the matrix-core kernels at (nearly) every density of a hard mask
             # (4096 x 264, a full mask: 4.7 ms on prebuilt lists, 5.3 ms on the matrix cores)
             if f is not None and not (small and f[1]) and (small or f[0] <= ops.MASK_LIST_DENSITY):

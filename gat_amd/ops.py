@@ -288,8 +288,14 @@ _density_cache = {}
 
 
 def graph_resident_batch(B, N):
-    """Batch shapes the graph-resident kernels take: at least 256 graphs of 4..320 nodes, a multiple of 4."""
+    """Batch shapes the mask-reading graph-resident kernels take: at least 256 graphs of 4..320 nodes, a multiple of 4."""
     return B >= 256 and N % 4 == 0 and 4 <= N <= 320
+
+
+def prebuilt_lists_batch(B, N):
+    """Batch shapes that can run on prebuilt lists (MaskLists): the same without the multiple of 4, which only the 16-byte
+    mask loads ask for — the reference's atlases have 246 and 90 nodes (Data_processing.py:46,518)."""
+    return B >= 256 and 4 <= N <= 320
 
 
 def _mask_facts(bias_mat):

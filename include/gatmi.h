@@ -442,7 +442,10 @@ int gatmi_dense_attn_bwd_fused(int64_t B, int32_t N, int32_t H, int32_t dp,
  *   gatmi_dense_attn_fwd_lists  gatmi_dense_attn_fwd_masked on the lists; GATMI_ERANGE when max_entries exceeds
  *                             the capacity.  A caller that understates max_entries gets wrong rows for the graphs
  *                             that exceed it, never an out-of-bounds access.
- * Shapes: those of the graph-resident kernels (see gatmi_dense_attn_bwd_fused). */
+ * Shapes: those of the graph-resident kernels (see gatmi_dense_attn_bwd_fused), except that N need not be a multiple
+ * of 4 (that is what the 16-byte mask loads of the mask-reading kernels ask for; the reference's atlases have 246 and
+ * 90 nodes, Data_processing.py:46,518): at least 256 graphs of 4..320 nodes, rows of 64 floats in heads of >= 8
+ * (one head of 64 floats: N % 4 == 0 for the backward pass). */
 int gatmi_dense_mask_bits(int64_t B, int32_t N, const float *bias_mat, float shared_limit, uint32_t *bits, void *stream);
 int gatmi_dense_lists_count(int64_t B, int32_t N, const uint32_t *bits, int32_t *row_cnt, int32_t *col_cnt, void *stream);
 int gatmi_dense_lists_fill(int64_t B, int32_t N, const uint32_t *bits, const int32_t *lptr, const int32_t *cptr,

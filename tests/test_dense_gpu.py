@@ -518,6 +518,52 @@ def test_prebuilt_lists_longer_than_one_fetch(B, N, F, H, D, density, drops):
     assert_close(res[1][1][:g].cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what="dX vs oracle")
 
 
+@pytest.mark.parametrize("B,N,F,H,D,drops", [(256, 246, 5, 8, 8, (0.0, 0.0)), (300, 90, 7, 4, 16, (0.6, 0.6)), (256, 90, 4, 2, 32, (0.0, 0.0)),
+                                              (256, 7, 3, 8, 8, (0.3, 0.0)), (256, 246, 6, 1, 64, (0.0, 0.0))])
+def test_prebuilt_lists_for_graphs_whose_size_is_not_a_multiple_of_four(B, N, F, H, D, drops):
+    """The reference's atlases have 246 and 90 nodes (Data_processing.py:46,518).  The mask-reading graph-resident kernels
+    need N % 4 == 0 for their 16-byte mask loads; kernels that walk prebuilt lists do not: MaskLists of such a batch
+    against the float64 oracle (first graphs) and against the mask given as a tensor (whole batch, other kernels:
+    tolerance).  One head of 64 floats has no list-walking backward kernel for these sizes and says so."""
+    from gat_amd import ops
+    from gat_amd.graph import MaskLists
+    dev = torch.device("cuda:0")
+    bm = torch.tensor(_masks(B, N, 0.15, 21 + N).astype(np.float32), device=dev)
+    ml = MaskLists(bm)
+    dp = ops.padded_width(D)
+    if H == 1:
+        assert not ml.fits(H, dp)
+        with pytest.raises(ValueError):
+            ops.dense_gat_layer(torch.zeros(B, N, F, device=dev), *[torch.zeros(s, device=dev) for s in ((F, H, D), (H, D), (H, D), (H,), (H,), (H, D))],
+                                ml, ops.make_cfg(H, D, "elu"))
+        return
+    assert ml.fits(H, dp)
+    p = layer_params(F, H, D, seed=N + 4)
+    x = np.random.default_rng(N + 5).normal(0, 1, (B, N, F)).astype(np.float32)
+    dout = np.random.default_rng(N + 6).normal(0, 1, (B, N, H * D)).astype(np.float32)
+    res = []
+    for mask in (ml, bm):
+        tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
+        xt = torch.tensor(x, device=dev, requires_grad=True)
+        cfg = ops.make_cfg(H, D, "elu", coef_drop=drops[0], in_drop=drops[1], training=True, seed=31, mask_path="lists")
+        out = ops.dense_gat_layer(xt, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], mask, cfg)
+        out.backward(torch.tensor(dout, device=dev))
+        res.append([out.detach(), xt.grad] + [tp[k].grad for k in ("W", "a1", "a2", "bias")])
+    for a, b, name in zip(res[0], res[1], ("out", "dX", "dW", "da1", "da2", "dbias")):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol_scale=5e-6, what="prebuilt lists vs mask tensor: " + name)
+    g = 2
+    coef_mask, ft_mask = dense_dropout_masks(31, B, N, H, D, dp, drops[0], drops[1])
+    rp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    rx = torch.tensor(x[:g].astype(np.float64), requires_grad=True)
+    ref = ref_torch.layer_dense(rx, rp, bm[:g].cpu().double(), "elu", "concat",
+                                coef_mask=None if coef_mask is None else torch.tensor(coef_mask[:g]),
+                                ft_mask=None if ft_mask is None else torch.tensor(ft_mask[:g]),
+                                coef_keep=1.0 - drops[0], ft_keep=1.0 - drops[1])
+    ref.backward(torch.tensor(dout[:g].astype(np.float64)))
+    assert_close(res[0][0][:g].cpu().numpy(), ref.detach().numpy(), what="forward vs oracle")
+    assert_close(res[0][1][:g].cpu().numpy(), rx.grad.numpy(), atol_scale=5e-6, what="dX vs oracle")
+
+
 def test_prebuilt_lists_refuse_masks_whose_biases_matter():
     from gat_amd.graph import MaskLists
     dev = torch.device("cuda:0")
@@ -530,8 +576,9 @@ def test_prebuilt_lists_refuse_masks_whose_biases_matter():
     everywhere[200, 5, :] = -1e9                               # a row masked everywhere: fp32 swallows its logits
     with pytest.raises(ValueError):
         MaskLists(torch.tensor(everywhere, device=dev))
+    assert MaskLists(torch.tensor(hard[:, :15, :15].copy(), device=dev)).N == 15      # any N from 4 to 320 ...
     with pytest.raises(ValueError):
-        MaskLists(torch.tensor(hard[:, :15, :15].copy(), device=dev))      # N not a multiple of 4
+        MaskLists(torch.tensor(hard[:, :3, :3].copy(), device=dev))      # ... but not below
 
 
 def test_mask_memo_switches_a_batch_of_small_graphs_to_prebuilt_lists():
@@ -557,6 +604,21 @@ def test_mask_memo_switches_a_batch_of_small_graphs_to_prebuilt_lists():
     changed = m(x, bt, "elu")
     assert not torch.equal(changed, calls[0])
     assert torch.equal(changed, m(x, bt, "elu")) and torch.equal(changed, m(x, bt, "elu"))
+    # graphs of 90 nodes (the reference's AAL atlas, not a multiple of 4): the lists are built on the FIRST sighting
+    odd = torch.tensor(_masks(B, 90, 0.1, 6).astype(np.float32), device=dev)
+    xo = torch.randn(B, 90, F, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    layers.mask_graphs._entries.clear()
+    first = m(xo, odd, "elu").detach().clone()
+    assert isinstance(layers.mask_graphs._entries[id(odd)][2], MaskLists)
+    assert torch.equal(first, m(xo, odd, "elu"))
+    from gat_amd import ops
+    tp = {k: getattr(m, k).detach() for k in ("W", "a1", "a2", "b1", "b2", "bias")}
+    layers.mask_graphs.enabled = False
+    try:
+        plain = ops.dense_gat_layer(xo, tp["W"], tp["a1"], tp["a2"], tp["b1"], tp["b2"], tp["bias"], odd, ops.make_cfg(H, D, "elu"))
+    finally:
+        layers.mask_graphs.enabled = True
+    assert_close(first.cpu().numpy(), plain.cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what="lists at first sighting vs the mask tensor")
 
 
 @pytest.mark.parametrize("B,N,F,H,D", [(256, 52, 6, 8, 8), (270, 100, 9, 4, 16)])
