@@ -175,7 +175,7 @@ def test_graph_resident_random_draw(seed):
     H, D = [(8, 8), (4, 16), (2, 32), (1, 64), (8, 7), (4, 13)][rng.integers(6)]
     dp = ops.padded_width(D)
     B = int(rng.integers(256, 300))
-    N = 4 * int(rng.integers(1, 31))
+    N = 4 * int(rng.integers(1, 31)) if rng.random() < 0.6 else int(rng.integers(4, 121))   # (any N: prebuilt lists only; the mask then runs other kernels)
     F = int(rng.choice([3, 8, 17, 24]))
     density = float(rng.choice([0.05, 0.15, 0.4] if N <= 60 else [0.05, 0.15]))     # (a million logits seldom all clear the kink)
     soft = bool(rng.random() < 0.25)
@@ -209,7 +209,8 @@ def test_graph_resident_random_draw(seed):
     dout = rng.normal(0, 1, tuple(ref.shape))
     ref.backward(torch.tensor(dout))
     results = []
-    for mask in ([bt] if soft else [bt, MaskLists(bt)]):
+    # (one head of 64 floats has no list-walking backward kernel for sizes that are not a multiple of 4)
+    for mask in ([bt] if soft or (H == 1 and N % 4) else [bt, MaskLists(bt)]):
         tp = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in p.items()}
         xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
         cfg = ops.make_cfg(H, D, activation, mask_path="lists", coef_drop=coef_drop, in_drop=in_drop, training=True, seed=sd, x_drop=x_drop)
@@ -220,7 +221,7 @@ def test_graph_resident_random_draw(seed):
         for k in ("W", "a1", "a2", "bias"):
             _close(tp[k].grad.cpu().numpy(), rp[k].grad.numpy(), what + " d" + k, atol_scale=5e-6)
         results.append([out.detach(), xt.grad] + [tp[k].grad for k in ("W", "a1", "a2", "b1", "b2", "bias")])
-    if len(results) == 2 and D == dp:          # (a padded head width changes nothing either, but keep the claim to the plain shapes)
+    if len(results) == 2 and D == dp and N % 4 == 0:          # (a padded head width changes nothing either, but keep the claim to the plain shapes)
         for a, b in zip(results[0][:3], results[1][:3]):            # out, dX, dW (the sums over all nodes: equal to rounding)
             assert torch.equal(a, b), what + ": prebuilt lists differ from the mask route"
 
