@@ -1,5 +1,5 @@
-import cProfile, pstats, torch, numpy as np, sys
-sys.path.insert(0, '/root/repo')
+import cProfile, os, pstats, torch, numpy as np, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gat_amd import ops
 from gat_amd.graph import MaskLists
 dev = torch.device('cuda:0')

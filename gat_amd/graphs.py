@@ -6,10 +6,11 @@ forward + backward is about 25 launches of a few microseconds each; eager execut
 the host issuing them, the replay is not.
 """
 import contextlib
+import warnings
 
 import torch
 
-from . import _lib
+from . import _hip_env, _lib
 
 _MASK64 = (1 << 64) - 1
 
@@ -52,7 +53,16 @@ def capture(step, warmup=3, fresh_dropout=True):
     coefficient and projected-feature masks (utils/layers.py:20,22), the forward and backward launches
     of one replay agree, and `replay.step_word` holds the count (gat_amd.graphs.stepped_seed gives the
     seed a replay used).  torch's own dropout of the layer input (:9) advances its generator under
-    replay by itself.  `fresh_dropout=False` replays the masks of the captured call unchanged."""
+    replay by itself.  `fresh_dropout=False` replays the masks of the captured call unchanged.
+
+    A graph whose packets the HIP runtime built once goes stale after several thousand eager launches
+    between capture and replay (gat_amd/_hip_env.py); importing this package before the process first
+    uses the GPU turns that mode off, and a capture in a process where it could not warns."""
+    if not _hip_env.replay_is_safe():
+        warnings.warn("%s was not 0 when this process first used the GPU: on this HIP runtime the replay of a graph "
+                      "can silently run with stale kernel arguments once a few thousand eager launches have been "
+                      "issued since its capture; export %s=0, or import gat_amd before the first GPU call"
+                      % (_hip_env.SWITCH, _hip_env.SWITCH), RuntimeWarning, stacklevel=2)
     device = torch.device("cuda", torch.cuda.current_device())
     word = torch.zeros(1, dtype=torch.int64, device=device) if fresh_dropout else None
     scope = dropout_step_word(word) if fresh_dropout else contextlib.nullcontext()

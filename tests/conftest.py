@@ -6,6 +6,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+try:
+    import gat_amd  # noqa: F401  (before anything touches the GPU: the import sets a switch the HIP runtime reads once)
+except ImportError:
+    pass                                                    # the tests that need the library say so themselves
 
 
 def pytest_configure(config):
