@@ -342,6 +342,8 @@ class BNFAttention(nn.Module):
             self.a2.uniform_(-lim_a, lim_a)
 
     def forward(self, seq, net_mat):
+        if self.heads <= 2:                                  # one sweep: no slices (each is an autograd node of its own)
+            return ops.bnf_aggregate(seq, net_mat, self.W, self.a1, self.a2, self.b1, self.b2, self.m1, self.m2)
         outs = []
         for h0 in range(0, self.heads, 2):                   # the kernels take one or two heads per sweep
             s = slice(h0, min(h0 + 2, self.heads))

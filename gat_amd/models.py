@@ -28,11 +28,16 @@ class TFAdam(torch.optim.Optimizer):
     first step).  For gradients of the size an L2 penalty alone produces the two take visibly
     different steps, so the drop-in keeps TensorFlow's form."""
 
-    def __init__(self, params, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-8, capturable=False):
+    def __init__(self, params, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-8, capturable=False, l2_coef=0.0):
         """capturable: keep the step count on the device and form lr_t there, so that step() issues
         the same launches with the same arguments every time and can be replayed from a HIP graph
-        (gat_amd.graphs.capture); the host-side count of the default mode would be frozen at capture."""
-        super().__init__(params, dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps, capturable=capturable))
+        (gat_amd.graphs.capture); the host-side count of the default mode would be frozen at capture.
+        l2_coef: add the gradient of the reference's penalty l2_coef * sum 0.5 ||v||^2
+        (base_gattn.py:77-79), l2_coef * v, to every variable's gradient here, in one fused launch
+        per few dozen variables, instead of through autograd (where it is a second contribution to
+        every variable: one more accumulation launch each); the loss then carries the penalty's value
+        only (BaseGAttN.training(..., penalty_in_optimizer=True))."""
+        super().__init__(params, dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps, capturable=capturable, l2_coef=l2_coef))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -61,6 +66,8 @@ class TFAdam(torch.optim.Optimizer):
                     self.state[p]["t"] = t
                 lr_t = group["lr"] * (1.0 - b2 ** t) ** 0.5 / (1.0 - b1 ** t)
             gs = [p.grad for p in ps]
+            if group["l2_coef"]:
+                gs = torch._foreach_add(gs, ps, alpha=group["l2_coef"])
             ms = [self.state[p]["m"] for p in ps]
             vs = [self.state[p]["v"] for p in ps]
             torch._foreach_mul_(ms, b1)
@@ -221,11 +228,21 @@ class BaseGAttN:
         return _L2Penalty.apply(float(l2_coef), *parameters)
 
     @staticmethod
-    def training(parameters, lr, l2_coef, capturable=False):
+    def training(parameters, lr, l2_coef, capturable=False, penalty_in_optimizer=False):
         """base_gattn.py:75-88 as (optimizer, penalty_fn).  Adam at a CONSTANT rate: the reference
         builds an exponential-decay schedule (:82) but never passes global_step to minimize (:86),
-        so the step counter stays 0 and the rate never decays.  capturable: see TFAdam."""
+        so the step counter stays 0 and the rate never decays.  capturable: see TFAdam.
+        penalty_in_optimizer: penalty_fn() returns the penalty's value without a gradient and the
+        optimizer adds l2_coef * v to each gradient itself (the same update, a launch per variable
+        fewer: worth it for networks of a hundred variables whose steps are a few milliseconds)."""
         parameters = list(parameters)
+        if penalty_in_optimizer:
+            opt = TFAdam(parameters, lr=lr, capturable=capturable, l2_coef=float(l2_coef))
+
+            def value():
+                with torch.no_grad():
+                    return BaseGAttN.l2_penalty(parameters, l2_coef)
+            return opt, value
         opt = TFAdam(parameters, lr=lr, capturable=capturable)
         return opt, (lambda: BaseGAttN.l2_penalty(parameters, l2_coef))
 

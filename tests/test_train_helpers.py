@@ -76,6 +76,29 @@ def test_adam_update_is_tensorflows():
     np.testing.assert_allclose(b.detach().numpy(), rb.numpy(), rtol=1e-12, atol=1e-15)
 
 
+def test_penalty_in_the_optimizer_takes_the_same_steps():
+    """base_gattn.py:77-86: the L2 penalty reaches Adam as l2_coef * v added to each gradient; through
+    autograd or added inside the optimizer, the variables after four steps are the same."""
+    rng = np.random.default_rng(1)
+    start = [rng.normal(0, 1, (4, 3)), rng.normal(0, 1, 5)]
+    x = torch.tensor(rng.normal(0, 1, (6, 4)))
+    results = []
+    for fused in (False, True):
+        vs = [torch.nn.Parameter(torch.tensor(t)) for t in start]
+        opt, l2 = BaseGAttN.training(vs, lr=0.01, l2_coef=0.05, penalty_in_optimizer=fused)
+        losses = []
+        for _ in range(4):
+            opt.zero_grad(set_to_none=True)
+            loss = ((x @ vs[0]).tanh().sum() + (vs[1] ** 2).sum()) + l2()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        results.append(([v.detach().numpy().copy() for v in vs], losses))
+    for a, b in zip(results[0][0], results[1][0]):
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(results[0][1], results[1][1], rtol=1e-12)
+
+
 def test_dropout_acts_on_the_rates_alone():
     """models/gat.py:8 accepts `training` and never reads it; utils/layers.py:8,19,21 test the rates."""
     assert _is_training(False, 0.6, 0.6) and _is_training(True, 0.0, 0.3) and _is_training(None, 0.1, 0.0)
