@@ -7,6 +7,7 @@ graphs differ in the strength of one block of connections; the node feature is t
 
     python examples/train_bnf_ae_like.py --steps 60
     python examples/train_bnf_ae_like.py --steps 60 --replay     # the training step replayed from a HIP graph
+    python examples/train_bnf_ae_like.py --nodes 246 --hid 64 --heads 6 --cam 256    # the sizes of BNF_AE.py:17-30,100
 
 --replay: at the reference's batch of 50 a step is several hundred launches of a few microseconds each and the host
 issuing them sets the pace; captured once (gat_amd.graphs.capture, Adam with its step count on the device) and
@@ -40,6 +41,9 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--batch", type=int, default=50)
     ap.add_argument("--nodes", type=int, default=90)
+    ap.add_argument("--hid", type=int, default=16, help="width of every attention round's output (BNF_AE.py:24 uses 64)")
+    ap.add_argument("--heads", type=int, default=2, help="attention heads per round (BNF_AE.py:25 uses 6)")
+    ap.add_argument("--cam", type=int, default=64, help="channels before the classifier (BNF_AE.py:100 uses 256)")
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--replay", action="store_true", help="capture the training step into a HIP graph and replay it")
     args = ap.parse_args()
@@ -47,7 +51,7 @@ def main():
     from gat_amd.models import BaseGAttN, GAT_AE_BNF_V2
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    model = GAT_AE_BNF_V2(1, args.nodes, 2, nb_CAM=64, hid_units=[16, 8, 8], n_heads=[2, 2, 2], device=dev)
+    model = GAT_AE_BNF_V2(1, args.nodes, 2, nb_CAM=args.cam, hid_units=[args.hid], n_heads=[args.heads], device=dev)
     opt, l2 = BaseGAttN.training(model.parameters(), lr=0.001, l2_coef=0.001, capturable=args.replay, penalty_in_optimizer=True)
     xv, wv, yv = synthetic_connectomes(200, args.nodes, dev, 1)
     # the step works on these three tensors; every iteration copies its batch into them

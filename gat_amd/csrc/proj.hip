@@ -824,6 +824,35 @@ static int launch_xt_gemm(const float *X, int64_t n, int F, int64_t ldx, const f
     return GATMI_OK;
 }
 
+// Column sums of a tall matrix Y [n, width] (row stride ld), first stage: block (b, slab) sums its run of rows for 64
+// columns; four rows in flight per thread, fixed order.  ws[b][width].
+__global__ __launch_bounds__(256) void column_partial_kernel(const float *Y, int64_t n, int width, int64_t ld, float *ws) {
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + tx;
+    const bool ok = c < width;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const float *col = Y + (ok ? c : 0);
+    for (int64_t r = r0 + ty; r < r1; r += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] += (ok && r + 4 * u < r1) ? col[(r + 4 * u) * ld] : 0.f;
+    }
+    part[ty][tx] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (ty == 0 && ok) ws[(int64_t)blockIdx.x * width + c] = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+}
+
+__global__ void column_total_kernel(const float *ws, int nblocks, int width, float *out) {
+    const int c = blockIdx.x * kSumCols + threadIdx.x;
+    const bool ok = c < width;
+    const float t = block_column_sum(nblocks, [&](int b) { return ok ? ws[(int64_t)b * width + c] : 0.f; });
+    if (ok && threadIdx.y == 0) out[c] = t;
+}
+
+static unsigned column_sum_blocks(int64_t n) { return (unsigned)std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 255) / 256)); }
+
 // preprocess_features (utils/process.py:155-162) for a CSR matrix: out = val / rowsum, rows that
 // sum to zero stay zero (r_inv = inf is replaced by 0 there).  One thread per row, stored order.
 __global__ void csr_row_normalize_kernel(int64_t n, const int64_t *rowptr, const float *val, float *out) {
@@ -1001,6 +1030,50 @@ extern "C" int gatmi_proj_bwd_params(const float *X, int64_t n, int32_t f_in, in
         }
         if (rc) return rc;
     }
+    return GATMI_OK;
+}
+
+static bool xt_lines_ok(const float *X, int64_t ldx, int f_in, const float *dY, int w) {
+    return ldx % 4 == 0 && f_in % 4 == 0 && w % 4 == 0 && aligned16(X) && aligned16(dY) && f_in <= 1024 && ldx < ((int64_t)1 << 29);
+}
+
+extern "C" size_t gatmi_linear_bwd_ws_floats(int64_t n, int32_t f_in, int32_t w) {
+    if (n <= 0 || f_in <= 0 || w <= 0) return 1;
+    const size_t gx = (size_t)std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 4 * kNodeChunk - 1) / (4 * kNodeChunk)));
+    const size_t fs = f_in <= 64 ? 64 : 128;
+    const size_t lines = gx * (((size_t)f_in + fs - 1) / fs * fs) * (((size_t)w + 63) / 64 * 64);
+    const int mt = dw_mt(f_in);
+    const size_t slabs = gx * ((size_t)((f_in + mt * 16 - 1) / (mt * 16)) * mt * 16) * 64;
+    return std::max(std::max(lines, slabs), (size_t)column_sum_blocks(n) * (size_t)w);
+}
+
+extern "C" int gatmi_linear_bwd_params(const float *X, int64_t n, int32_t f_in, int64_t ldx, const float *dY, int32_t w,
+                                       float *dW, float *db, float *ws, void *stream) {
+    GATMI_REQUIRE(n >= 0 && f_in > 0 && w > 0 && ldx >= f_in, GATMI_EINVAL, "linear_bwd_params: bad dims");
+    GATMI_REQUIRE(n < ((int64_t)1 << 31), GATMI_ERANGE, "linear_bwd_params: more than 2^31 rows");
+    GATMI_REQUIRE(X && dY && dW && ws, GATMI_EINVAL, "linear_bwd_params: null pointer");
+    GATMI_REQUIRE_ALIGNED(ws);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc = GATMI_OK;
+    if (xt_lines_ok(X, ldx, f_in, dY, w)) {
+        rc = launch_xt_lines(X, n, f_in, ldx, dY, w, ws, dW, InDrop{}, st);
+    } else {
+        for (int c0 = 0; c0 < w && !rc; c0 += 64) {          // column slabs share the workspace: the stream orders them
+            const int cw = std::min(64, w - c0);
+            switch (dw_mt(f_in)) {
+                case 1: rc = launch_xt_gemm<1>(X, n, f_in, ldx, dY + c0, w, cw, ws, dW + c0, st); break;
+                case 2: rc = launch_xt_gemm<2>(X, n, f_in, ldx, dY + c0, w, cw, ws, dW + c0, st); break;
+                case 4: rc = launch_xt_gemm<4>(X, n, f_in, ldx, dY + c0, w, cw, ws, dW + c0, st); break;
+                default: rc = launch_xt_gemm<7>(X, n, f_in, ldx, dY + c0, w, cw, ws, dW + c0, st); break;
+            }
+        }
+    }
+    if (rc || !db) return rc;
+    const unsigned nb = column_sum_blocks(n);
+    hipLaunchKernelGGL(column_partial_kernel, dim3(nb, (unsigned)((w + 63) / 64)), dim3(256), 0, st, dY, n, w, (int64_t)w, ws);
+    GATMI_LAUNCH_CHECK("column_partial");
+    hipLaunchKernelGGL(column_total_kernel, dim3((unsigned)((w + kSumCols - 1) / kSumCols)), dim3(kSumCols, kSumRows), 0, st, ws, (int)nb, w, db);
+    GATMI_LAUNCH_CHECK("column_total");
     return GATMI_OK;
 }
 

@@ -359,6 +359,13 @@ def InnerProductDecoder(seq, activation="sigmoid", dropout=0.0):
     return ops.inner_product_decoder(seq, activation, dropout).reshape(-1)
 
 
+def _linear(layer, x):
+    """A width-1 convolution of the reference (tf.layers.conv1d(x, out, 1)) held as torch.nn.Linear, or the identity."""
+    if isinstance(layer, nn.Identity):
+        return x
+    return ops.tall_linear(x, layer.weight, layer.bias)
+
+
 class AttnE2VBNFV2(nn.Module):
     """`attn_e2v_BNF_V2` (utils/layers.py:158-227): `reps` (5 in the reference, :171) rounds of
     n_heads brain-network attention steps (BNFAttention: the libgatmi kernels), each head followed
@@ -397,13 +404,13 @@ class AttnE2VBNFV2(nn.Module):
         for rep in range(self.reps):
             agg = self.att[rep](seq_out, net_mat)                                        # [B,N,H,F]   layers.py:174-179
             heads = self._act(torch.einsum("bnhf,hfo->bnho", agg, self.head_w[rep]) + self.head_b[rep])   # :180
-            merged = self._act(self.merge[rep](heads.flatten(2)))                       # :182-183
+            merged = self._act(_linear(self.merge[rep], heads.flatten(2)))              # :182-183
             if self.residual:
-                seq_out = merged + self.res[rep](seq_out)                               # :185-189
+                seq_out = merged + _linear(self.res[rep], seq_out)                      # :185-189
             else:
                 seq_out = merged
             outs.append(seq_out)
         aggall = torch.cat(outs, dim=-1)
-        out = self._act(self.out2(self._act(self.out1(aggall))))
+        out = self._act(_linear(self.out2, self._act(_linear(self.out1, aggall))))
         out = out / torch.sqrt(torch.clamp((out * out).sum(dim=-2, keepdim=True), min=1e-12))   # tf.nn.l2_normalize(axis=-2)
         return out, aggall

@@ -669,6 +669,56 @@ def bnf_aggregate(x, net_mat, W, a1, a2, b1, b2, m1, m2, slope=LEAKY_SLOPE):
     return BnfAggregateFn.apply(x, net_mat, W, a1, a2, b1, b2, m1, m2, float(slope))
 
 
+class TallLinearFn(torch.autograd.Function):
+    """y = x . W^T + b for x [n, f_in] (rows may be strided), W [w, f_in] and b [w] laid out as torch.nn.Linear keeps
+    them: the width-1 convolutions around the brain-network attention step (utils/layers.py:180,183,187,223-224).
+    Forward and input gradient are ordinary GEMMs (torch); the parameter gradients, reductions over the n rows, run on
+    gatmi_linear_bwd_params."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        _require_cuda(x, W)
+        y = torch.addmm(b, x, W.t()) if b is not None else x @ W.t()
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        n, f_in = x.shape
+        w = W.shape[0]
+        dy = _f32(dy).contiguous()
+        dx = dy @ W if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            if x.stride(1) != 1:
+                x = x.contiguous()
+            dWt = _new((f_in, w), dy)
+            db = _new((w,), dy) if ctx.has_bias else None
+            ws = _new((_lib.lib.gatmi_linear_bwd_ws_floats(n, f_in, w),), dy)
+            _lib.call("gatmi_linear_bwd_params", ptr(x), n, f_in, x.stride(0), ptr(dy), w, ptr(dWt), ptr(db), ptr(ws), _lib.current_stream())
+            dW = dWt.t()
+        return dx, dW, db
+
+
+TALL_LINEAR_ROWS = 1024      # below this many rows the layer stays with torch's own backward
+
+
+def tall_linear(x, weight, bias=None):
+    """torch.nn.functional.linear for inputs of many rows and modest widths (x [..., f_in] on the GPU, fp32): same
+    result, parameter gradients from the library's fixed-order reductions."""
+    lead = x.shape[:-1]
+    n = 1
+    for d in lead:
+        n *= int(d)
+    if not x.is_cuda or x.dtype != torch.float32 or n < TALL_LINEAR_ROWS or not torch.is_grad_enabled():
+        return torch.nn.functional.linear(x, weight, bias)
+    if x.dim() == 2:
+        return TallLinearFn.apply(x, weight, bias)
+    return TallLinearFn.apply(x.reshape(n, x.shape[-1]), weight, bias).reshape(*lead, weight.shape[0])
+
+
 class InnerProductDecoderFn(torch.autograd.Function):
     """utils/layers.py:307-313: act(dropout(z) . dropout(z)^T) per graph, z [B,N,F] -> [B,N,N]."""
 

@@ -165,6 +165,16 @@ int gatmi_proj_bwd_input(const float *dWh, int64_t n, int32_t f_in, const float 
                          int32_t H, int32_t dp, float *dX, int64_t lddx, int accumulate,
                          float in_keep, uint64_t seed, void *stream);
 
+/* Parameter gradients of an ordinary dense layer Y = X.W + b applied to every node row: the width-1 convolutions
+ * around the brain-network attention step (tf.layers.conv1d(., out_sz, 1), utils/layers.py:180,183,187,223-224;
+ * models/gat.py:212,231).  With n in the tens of thousands and widths of 16..384 these are reductions over n, which
+ * a general GEMM library runs in a dozen workgroups; here the rows are split over the grid and summed in a fixed order.
+ *   X [n, f_in] (row stride ldx floats), dY [n, w] contiguous  ->  dW [f_in, w] = X^T . dY,  db [w] = column sums of dY
+ *   (db = NULL to skip).  ws: gatmi_linear_bwd_ws_floats(n, f_in, w) floats, 16-byte aligned. */
+size_t gatmi_linear_bwd_ws_floats(int64_t n, int32_t f_in, int32_t w);
+int gatmi_linear_bwd_params(const float *X, int64_t n, int32_t f_in, int64_t ldx, const float *dY, int32_t w,
+                            float *dW, float *db, float *ws, void *stream);
+
 /* The projection for SPARSE node features: X [n, f_in] in CSR (xrowptr [n+1], xcol, xval in DEVICE
  * memory), as the sparse tuple of preprocess_features (utils/process.py:155-162, the second return
  * value) describes it; Cora's features are 98.7 % zeros.  Wh = X . W summed over stored entries

@@ -106,3 +106,35 @@ def test_gat_ae_bnf_v2_model_runs_on_the_kernels():
     (digits.sum() + rec_a.mean() + rec_b.mean()).backward()
     missing = [n for n, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
     assert not missing, missing
+
+
+@pytest.mark.parametrize("n,f_in,w,strided", [(5000, 384, 64, False), (4500, 16, 16, False), (12300, 64, 64, True), (3000, 1, 64, False),
+                                               (2500, 320, 64, False), (2048, 128, 256, False), (1500, 10, 6, False), (1100, 64, 7, True)])
+def test_tall_linear_matches_the_plain_dense_layer(n, f_in, w, strided):
+    """The width-1 convolutions of utils/layers.py:180,183,187,223-224 as a dense layer over all node rows: output
+    and input gradient are torch's GEMMs, weight and bias gradients come from the library's reductions over the rows;
+    all against a float64 evaluation."""
+    from gat_amd import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n + f_in + w)
+    x64 = torch.tensor(rng.normal(0, 1, (n, 3 * f_in if strided else f_in)), requires_grad=True)
+    W64 = torch.tensor(rng.normal(0, 0.3, (w, f_in)), requires_grad=True)
+    b64 = torch.tensor(rng.normal(0, 0.3, w), requires_grad=True)
+    dy = torch.tensor(rng.normal(0, 1, (n, w)))
+    xs64 = x64[:, f_in:2 * f_in] if strided else x64
+    (torch.nn.functional.linear(xs64, W64, b64) * dy).sum().backward()
+    x = x64.detach().to(dev, torch.float32).requires_grad_(True)
+    W = W64.detach().to(dev, torch.float32).requires_grad_(True)
+    b = b64.detach().to(dev, torch.float32).requires_grad_(True)
+    xs = x[:, f_in:2 * f_in] if strided else x
+    y = ops.tall_linear(xs, W, b)
+    assert y.grad_fn is not None and "TallLinearFn" in type(y.grad_fn).__name__
+    assert_close(y.detach().cpu().numpy(), torch.nn.functional.linear(xs64, W64, b64).detach().numpy(), what="tall linear forward")
+    y.backward(dy.to(dev, torch.float32))
+    assert_close(W.grad.cpu().numpy(), W64.grad.numpy(), what="tall linear dW")
+    assert_close(b.grad.cpu().numpy(), b64.grad.numpy(), what="tall linear db")
+    assert_close(x.grad.cpu().numpy(), x64.grad.numpy(), what="tall linear dX")
+    # without a bias, and below the row limit the layer is torch's own
+    y2 = ops.tall_linear(xs, W)
+    y2.backward(dy.to(dev, torch.float32))
+    assert ops.tall_linear(xs[:100], W, b).grad_fn is not None and "TallLinearFn" not in type(ops.tall_linear(xs[:100], W, b).grad_fn).__name__
