@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--hid", type=int, default=16, help="width of every attention round's output (BNF_AE.py:24 uses 64)")
     ap.add_argument("--heads", type=int, default=2, help="attention heads per round (BNF_AE.py:25 uses 6)")
     ap.add_argument("--cam", type=int, default=64, help="channels before the classifier (BNF_AE.py:100 uses 256)")
+    ap.add_argument("--no-dropout", action="store_true", help="leave out the dropout of models/gat.py:209-210: eager and replayed runs then print the same losses")
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--replay", action="store_true", help="capture the training step into a HIP graph and replay it")
     args = ap.parse_args()
@@ -60,18 +61,21 @@ def main():
 
     def train_step():
         opt.zero_grad(set_to_none=True)       # under replay the gradients live in the graph's own pool, at fixed addresses
-        digits, rec_a, rec_b, _, _ = model(x, w, training=True)
+        digits, rec_a, rec_b, _, _ = model(x, w, training=not args.no_dropout)
         target = (w > 0).float()                                            # reconstruct which pairs are connected
         loss = BaseGAttN.AE_classify_loss(digits, y, target, rec_a, target, rec_b, 1.0) + l2()
         loss.backward()
         opt.step()
         loss_out.copy_(loss.detach())
 
-    done = 0
+    # both modes start with two steps on the first batch: the warm-up calls of graphs.capture are real training
+    # steps (the captured call itself only records its launches)
+    done = 2
     if args.replay:
-        # the warm-up calls of the capture are real training steps (on the first batch)
         train_step, _ = graphs.capture(train_step, warmup=2)
-        done = 3
+    else:
+        for _ in range(done):
+            train_step()
     first = last = None
     torch.cuda.synchronize()
     t0 = time.time()

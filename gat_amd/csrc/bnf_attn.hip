@@ -32,6 +32,7 @@ struct BnfFwdArgs {
     const float *X, *A, *f1, *f2, *m1, *m2;
     float *out, *t2n, *t2pos, *lse, *q;
     float slope;
+    int64_t ld_out;             // floats between rows of out (>= H * FP): a call may fill its heads' share of wider rows
 };
 
 // Block (b, 64 destination rows): wave w owns rows 16*w .. 16*w+15 and all H heads.
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
                 if (c < FP) {
                     const int64_t o = (node * H + h) * FP + c;
                     const float t2 = acc2[h][nt][r] * inv;
-                    a.out[o] = m1v[h] * (m2v[h] * accU[nt][r] + accV[nt][r]) + t2;
+                    a.out[node * a.ld_out + h * FP + c] = m1v[h] * (m2v[h] * accU[nt][r] + accV[nt][r]) + t2;
                     if constexpr (SAVE) {
                         a.t2n[o] = t2;
                         a.t2pos[o] = acc2p[h][nt][r] * inv;
@@ -189,6 +190,7 @@ struct BnfBwdArgs {
     const float *G, *stats, *X, *A, *f2, *m1, *m2;
     float *dX, *dA, *df2, *ws;
     float slope;
+    int accumulate;             // dX, dA: add to what is there (a later group of heads of the same step)
 };
 
 // Block (b, 64 sources): wave w owns sources 16*w .. 16*w+15, all heads, and walks all destinations.
@@ -292,7 +294,10 @@ __global__ __launch_bounds__(256) void bnf_attn_bwd_kernel(BnfBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = ic + il + 4 * kq + r;
-                if (ok[r]) a.dA[(b * N + i) * (int64_t)N + jcol] = dA[r];
+                if (ok[r]) {
+                    float *p = a.dA + (b * N + i) * (int64_t)N + jcol;
+                    *p = a.accumulate ? *p + dA[r] : dA[r];
+                }
             }
         }
     }
@@ -330,7 +335,10 @@ __global__ __launch_bounds__(256) void bnf_attn_bwd_kernel(BnfBwdArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int c = 16 * nt + m;
-            if (c < FP) a.dX[(b * N + j) * (int64_t)FP + c] = acc[nt][r];
+            if (c < FP) {
+                float *p = a.dX + (b * N + j) * (int64_t)FP + c;
+                *p = a.accumulate ? *p + acc[nt][r] : acc[nt][r];
+            }
         }
     }
 }
@@ -359,17 +367,19 @@ static int bnf_check(int64_t B, int32_t N, int32_t H, int32_t fp, const char *na
 extern "C" int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
                                   const float *X, const float *A, const float *f1, const float *f2,
                                   const float *m1, const float *m2, float slope,
-                                  float *out, float *t2n, float *t2pos, float *lse, float *q, void *stream) {
+                                  float *out, int64_t ld_out, float *t2n, float *t2pos, float *lse, float *q, void *stream) {
     int rc = bnf_check(B, N, H, fp, "bnf_attn_fwd");
     if (rc) return rc;
     if (B == 0 || N == 0) return GATMI_OK;
     GATMI_REQUIRE(X && A && f1 && f2 && m1 && m2 && out, GATMI_EINVAL, "bnf_attn_fwd: null pointer");
+    if (ld_out == 0) ld_out = (int64_t)H * fp;
+    GATMI_REQUIRE(ld_out >= (int64_t)H * fp, GATMI_EINVAL, "bnf_attn_fwd: ld_out %lld is less than the %d floats of a row", (long long)ld_out, H * fp);
     const bool save = t2n || t2pos || lse || q;
     GATMI_REQUIRE(!save || (t2n && t2pos && lse && q), GATMI_EINVAL, "bnf_attn_fwd: t2n, t2pos, lse, q must be given together");
     GATMI_REQUIRE_ALIGNED(X); GATMI_REQUIRE_ALIGNED(A);
     BnfFwdArgs a;
     a.N = N; a.X = X; a.A = A; a.f1 = f1; a.f2 = f2; a.m1 = m1; a.m2 = m2;
-    a.out = out; a.t2n = t2n; a.t2pos = t2pos; a.lse = lse; a.q = q; a.slope = slope;
+    a.out = out; a.t2n = t2n; a.t2pos = t2pos; a.lse = lse; a.q = q; a.slope = slope; a.ld_out = ld_out;
     const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X_(ff, hh)                                                                                  \
@@ -391,7 +401,7 @@ extern "C" size_t gatmi_bnf_attn_bwd_ws_floats(int64_t B, int32_t N, int32_t H) 
 extern "C" int gatmi_bnf_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t fp,
                                   const float *G, const float *stats, const float *X, const float *A,
                                   const float *f2, const float *m1, const float *m2, float slope,
-                                  float *dX, float *dA, float *df2, float *dm, float *ws, void *stream) {
+                                  float *dX, float *dA, int accumulate, float *df2, float *dm, float *ws, void *stream) {
     int rc = bnf_check(B, N, H, fp, "bnf_attn_bwd");
     if (rc) return rc;
     if (B == 0 || N == 0) return GATMI_OK;
@@ -399,7 +409,7 @@ extern "C" int gatmi_bnf_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t fp,
     GATMI_REQUIRE_ALIGNED(G);
     BnfBwdArgs a;
     a.N = N; a.G = G; a.stats = stats; a.X = X; a.A = A; a.f2 = f2; a.m1 = m1; a.m2 = m2;
-    a.dX = dX; a.dA = dA; a.df2 = df2; a.ws = ws; a.slope = slope;
+    a.dX = dX; a.dA = dA; a.df2 = df2; a.ws = ws; a.slope = slope; a.accumulate = accumulate;
     const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X_(ff, hh)                                                                         \

@@ -342,14 +342,7 @@ class BNFAttention(nn.Module):
             self.a2.uniform_(-lim_a, lim_a)
 
     def forward(self, seq, net_mat):
-        if self.heads <= 2:                                  # one sweep: no slices (each is an autograd node of its own)
-            return ops.bnf_aggregate(seq, net_mat, self.W, self.a1, self.a2, self.b1, self.b2, self.m1, self.m2)
-        outs = []
-        for h0 in range(0, self.heads, 2):                   # the kernels take one or two heads per sweep
-            s = slice(h0, min(h0 + 2, self.heads))
-            outs.append(ops.bnf_aggregate(seq, net_mat, self.W[:, s].contiguous(), self.a1[s], self.a2[s], self.b1[s],
-                                          self.b2[s], self.m1[s], self.m2[s]))
-        return torch.cat(outs, dim=2)
+        return ops.bnf_aggregate(seq, net_mat, self.W, self.a1, self.a2, self.b1, self.b2, self.m1, self.m2)
 
 
 def InnerProductDecoder(seq, activation="sigmoid", dropout=0.0):

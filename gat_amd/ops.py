@@ -593,76 +593,104 @@ def dense_gat_layer(x, W, a1, a2, b1, b2, bias, bias_mat, cfg, W_res=None, b_res
 
 
 class BnfAggregateFn(torch.autograd.Function):
-    """Inner step of the reference's attn_e2v_BNF_V2 (utils/layers.py:174-179, coefficients from
-    attn_v2e_BNF_V2 :229-237) for H <= 2 heads sharing x and the weighted adjacency:
+    """Inner step of the reference's attn_e2v_BNF_V2 (utils/layers.py:173-179, coefficients from
+    attn_v2e_BNF_V2 :229-237) for H heads sharing x and the weighted adjacency:
         out[b,i,h,:] = sum_j (m2_h [A_ij>0] + A_ij) (m1_h + softmax_j LeakyReLU(f1_i + f2_j)) x[b,j,:]
-    x [B,N,F], net_mat [B,N,N], W [F,H,Dz], a1,a2 [H,Dz], b1,b2,m1,m2 [H]  ->  [B,N,H,F]."""
+    x [B,N,F], net_mat [B,N,N], W [F,H,Dz], a1,a2 [H,Dz], b1,b2,m1,m2 [H]  ->  [B,N,H,F].
+    The kernels sweep two heads per launch; the groups of one step are issued from this one autograd node (slices of
+    the variables taken per group outside would each be a node of their own, with a zero-filled full-size gradient and
+    an accumulation per slice): every group's output lands in its share of the same rows, and the gradients of x and
+    of the adjacency are added up by the kernels."""
 
     @staticmethod
     def forward(ctx, x, net_mat, W, a1, a2, b1, b2, m1, m2, slope):
         _require_cuda(x, net_mat, W)
         B, N, F = x.shape
         H, Dz = a1.shape
-        if H not in (1, 2) or F > 64:
-            raise ValueError("BnfAggregateFn: heads must be 1 or 2 per call and the feature width <= 64 (got %d, %d)" % (H, F))
+        if F > 64:
+            raise ValueError("BnfAggregateFn: feature width %d > 64" % F)
         fp = padded_width(F)
         n = B * N
         st = _lib.current_stream()
         xp = _pad_last(_f32(x).reshape(n, F), F, fp)
         A = _f32(net_mat).contiguous()
-        cfg = make_cfg(H, Dz, "identity", "concat", slope=slope)
-        Wfull = torch.zeros((fp, H, Dz), dtype=torch.float32, device=x.device)
-        Wfull[:F] = W.reshape(F, H, Dz)
-        Wp, a1p, a2p, _, Z, f1, f2, _ = _project(xp, Wfull, a1, a2, b1, b2, cfg)
+        Wfull = W.reshape(F, H, Dz)
+        if fp != F:
+            Wfull = torch.zeros((fp, H, Dz), dtype=torch.float32, device=x.device)
+            Wfull[:F] = W.reshape(F, H, Dz)
         m1c, m2c = m1.reshape(H).contiguous(), m2.reshape(H).contiguous()
         out = _new((n, H * fp), x)
         need_grad = any(ctx.needs_input_grad)
-        t2n = t2pos = lse = q = None
+        groups = []
+        for h0 in range(0, H, 2):
+            s = slice(h0, min(h0 + 2, H))
+            hg = s.stop - s.start
+            cfg = make_cfg(hg, Dz, "identity", "concat", slope=slope)
+            Wp, a1p, a2p, _, Z, f1, f2, _ = _project(xp, Wfull[:, s], a1[s], a2[s], b1[s], b2[s], cfg)
+            t2n = t2pos = lse = q = None
+            if need_grad:
+                t2n, t2pos = _new((n, hg * fp), x), _new((n, hg * fp), x)
+                lse, q = _new((n, hg), x), _new((n, hg), x)
+            _lib.call("gatmi_bnf_attn_fwd", B, N, hg, fp, ptr(xp), ptr(A), ptr(f1), ptr(f2), ptr(m1c[s]), ptr(m2c[s]), slope,
+                      ptr(out[:, h0 * fp:]), H * fp, ptr(t2n), ptr(t2pos), ptr(lse), ptr(q), st)
+            groups.append((cfg, [Wp, a1p, a2p, Z, f1, f2, t2n, t2pos, lse, q]))
         if need_grad:
-            t2n, t2pos = _new((n, H * fp), x), _new((n, H * fp), x)
-            lse, q = _new((n, H), x), _new((n, H), x)
-        _lib.call("gatmi_bnf_attn_fwd", B, N, H, fp, ptr(xp), ptr(A), ptr(f1), ptr(f2), ptr(m1c), ptr(m2c), slope,
-                  ptr(out), ptr(t2n), ptr(t2pos), ptr(lse), ptr(q), st)
-        if need_grad:
-            ctx.dims, ctx.cfg, ctx.slope = (B, N, F, H, Dz, fp), cfg, slope
-            ctx.save_for_backward(xp, A, Wp, a1p, a2p, Z, f1, f2, m1c, m2c, t2n, t2pos, lse, q)
+            ctx.dims, ctx.slope, ctx.cfgs = (B, N, F, H, Dz, fp), slope, [c for c, _ in groups]
+            ctx.save_for_backward(xp, A, m1c, m2c, *[t for _, ts in groups for t in ts])
         return out.reshape(B, N, H, fp)[..., :F]
 
     @staticmethod
     def backward(ctx, dout):
-        xp, A, Wp, a1p, a2p, Z, f1, f2, m1c, m2c, t2n, t2pos, lse, q = ctx.saved_tensors
+        xp, A, m1c, m2c = ctx.saved_tensors[:4]
+        per_group = ctx.saved_tensors[4:]
         B, N, F, H, Dz, fp = ctx.dims
-        cfg, slope = ctx.cfg, ctx.slope
+        slope = ctx.slope
         n = B * N
         st = _lib.current_stream()
-        G = _pad_last(dout.reshape(n, H, F), F, fp).reshape(n, H * fp)
-        g = _new((n, H * fp), xp)
-        stats = _new((n, 3 * H), xp)
-        df1 = _new((n, H), xp)
-        ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(H, fp),), xp)
-        _lib.call("gatmi_gat_bwd_node", n, H, fp, ptr(G), None, ptr(t2n), ptr(t2pos), ptr(q), ptr(f1), ptr(lse), None,
-                  _lib.ACT_IDENTITY, _lib.REDUCE_CONCAT, slope, ptr(g), H * fp, None, 0, ptr(stats), 3 * H, ptr(df1), None, ptr(ws), st)
+        n_groups = len(ctx.cfgs)
+        G_all = _pad_last(dout.reshape(n, H, F), F, fp)                     # [n, H, fp]
+        if n_groups > 1 and H % 2 == 0:
+            G_all = G_all.reshape(n, n_groups, 2 * fp).transpose(0, 1).contiguous()      # every group's rows contiguous
         dx = _new((n, fp), xp)
         dA = _new((B, N, N), xp)
-        df2 = _new((n, H), xp)
-        dm = _new((2 * H,), xp)
-        ws2 = _new((max(1, _lib.lib.gatmi_bnf_attn_bwd_ws_floats(B, N, H)),), xp)
-        _lib.call("gatmi_bnf_attn_bwd", B, N, H, fp, ptr(g), ptr(stats), ptr(xp), ptr(A), ptr(f2), ptr(m1c), ptr(m2c), slope,
-                  ptr(dx), ptr(dA), ptr(df2), ptr(dm), ptr(ws2), st)
-        # the projection only feeds the logit halves: dZ = df1 a1 + df2 a2
-        dZ = torch.zeros((n, H * cfg.dp), dtype=torch.float32, device=xp.device)
-        _lib.call("gatmi_gat_bwd_finalize", n, H, cfg.dp, ptr(df1), ptr(df2), ptr(a1p), ptr(a2p), ptr(dZ), st)
-        wsp = _new((_lib.lib.gatmi_proj_bwd_ws_floats(fp, H, cfg.dp),), xp)
-        hd = H * cfg.dp
-        dW = _new((fp, hd), xp)
-        da1, da2 = _new((hd,), xp), _new((hd,), xp)
+        dp = ctx.cfgs[0].dp
+        dW = _new((fp, H, dp), xp)
+        da1, da2 = _new((H, dp), xp), _new((H, dp), xp)
         db1, db2 = _new((H,), xp), _new((H,), xp)
-        _lib.call("gatmi_proj_bwd_params", ptr(xp), n, fp, fp, ptr(dZ), ptr(Z), ptr(df1), ptr(df2), H, cfg.dp,
-                  ptr(dW), ptr(da1), ptr(da2), ptr(db1), ptr(db2), ptr(wsp), 1.0, 0, st)
-        _lib.call("gatmi_proj_bwd_input", ptr(dZ), n, fp, ptr(Wp), H, cfg.dp, ptr(dx), fp, 1, 1.0, 0, st)
-        unp = lambda t, lead: t.reshape(*lead, H, cfg.dp)[..., :Dz]
-        return (dx[:, :F].reshape(B, N, F), dA, unp(dW, (fp,))[:F], unp(da1, ()), unp(da2, ()), db1, db2,
-                dm[:H], dm[H:], None)
+        dm = _new((2, H), xp)
+        for gi, cfg in enumerate(ctx.cfgs):
+            Wp, a1p, a2p, Z, f1, f2, t2n, t2pos, lse, q = per_group[10 * gi:10 * gi + 10]
+            h0, hg = 2 * gi, cfg.H
+            if n_groups == 1:
+                G = G_all.reshape(n, hg * fp)
+            elif H % 2 == 0:
+                G = G_all[gi]
+            else:
+                G = G_all[:, h0:h0 + hg].reshape(n, hg * fp).contiguous()
+            g = _new((n, hg * fp), xp)
+            stats = _new((n, 3 * hg), xp)
+            df1 = _new((n, hg), xp)
+            ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(hg, fp),), xp)
+            _lib.call("gatmi_gat_bwd_node", n, hg, fp, ptr(G), None, ptr(t2n), ptr(t2pos), ptr(q), ptr(f1), ptr(lse), None,
+                      _lib.ACT_IDENTITY, _lib.REDUCE_CONCAT, slope, ptr(g), hg * fp, None, 0, ptr(stats), 3 * hg, ptr(df1), None, ptr(ws), st)
+            df2 = _new((n, hg), xp)
+            dmg = _new((2 * hg,), xp)
+            ws2 = _new((max(1, _lib.lib.gatmi_bnf_attn_bwd_ws_floats(B, N, hg)),), xp)
+            _lib.call("gatmi_bnf_attn_bwd", B, N, hg, fp, ptr(g), ptr(stats), ptr(xp), ptr(A), ptr(f2), ptr(m1c[h0:]), ptr(m2c[h0:]), slope,
+                      ptr(dx), ptr(dA), int(gi > 0), ptr(df2), ptr(dmg), ptr(ws2), st)
+            dm[:, h0:h0 + hg] = dmg.reshape(2, hg)
+            # the projection only feeds the logit halves: dZ = df1 a1 + df2 a2
+            hd = hg * dp
+            dZ = torch.zeros((n, hd), dtype=torch.float32, device=xp.device)
+            _lib.call("gatmi_gat_bwd_finalize", n, hg, dp, ptr(df1), ptr(df2), ptr(a1p), ptr(a2p), ptr(dZ), st)
+            wsp = _new((_lib.lib.gatmi_proj_bwd_ws_floats(fp, hg, dp),), xp)
+            dWg = dW if n_groups == 1 else _new((fp, hd), xp)
+            _lib.call("gatmi_proj_bwd_params", ptr(xp), n, fp, fp, ptr(dZ), ptr(Z), ptr(df1), ptr(df2), hg, dp,
+                      ptr(dWg), ptr(da1[h0:]), ptr(da2[h0:]), ptr(db1[h0:]), ptr(db2[h0:]), ptr(wsp), 1.0, 0, st)
+            if n_groups > 1:
+                dW[:, h0:h0 + hg] = dWg.reshape(fp, hg, dp)
+            _lib.call("gatmi_proj_bwd_input", ptr(dZ), n, fp, ptr(Wp), hg, dp, ptr(dx), fp, 1, 1.0, 0, st)
+        return (dx[:, :F].reshape(B, N, F), dA, dW[:F, :, :Dz], da1[:, :Dz], da2[:, :Dz], db1, db2, dm[0], dm[1], None)
 
 
 def bnf_aggregate(x, net_mat, W, a1, a2, b1, b2, m1, m2, slope=LEAKY_SLOPE):

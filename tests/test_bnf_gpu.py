@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("B,N,F,H,Dz", [(3, 90, 1, 2, 64), (2, 246, 64, 2, 64), (2, 70, 16, 1, 64), (4, 33, 5, 2, 16),
-                                         (1, 264, 64, 3, 64)])
+                                         (1, 264, 64, 3, 64), (2, 90, 16, 6, 64), (2, 50, 3, 4, 32), (2, 60, 8, 5, 16)])
 def test_bnf_aggregate_forward_and_gradients(B, N, F, H, Dz):
     from gat_amd.layers import BNFAttention
     dev = torch.device("cuda:0")
