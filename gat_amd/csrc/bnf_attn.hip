@@ -32,7 +32,8 @@ struct BnfFwdArgs {
     const float *X, *A, *f1, *f2, *m1, *m2;
     float *out, *t2n, *t2pos, *lse, *q;
     float slope;
-    int64_t ld_out;             // floats between rows of out (>= H * FP): a call may fill its heads' share of wider rows
+    int64_t ld_out;             // floats between rows of out (>= groups * H * FP): a call may fill its heads' share of wider rows
+    int64_t nodes;              // B * N: group g (blockIdx.z) reads f1, f2 at + g * nodes * H, saves at + g * nodes * H (* FP)
 };
 
 // Block (b, 64 destination rows): wave w owns rows 16*w .. 16*w+15 and all H heads.
@@ -50,6 +51,12 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
     const int i0 = blockIdx.y * 64 + wave * 16;
     const int irow = min(i0 + m, N - 1);
     const float *arow = a.A + (b * N + irow) * (int64_t)N;
+    // a group of H heads per blockIdx.z: its own logit halves, scalars and saved tensors, its share of the output rows
+    const int64_t goff = (int64_t)blockIdx.z * a.nodes * H;
+    a.f1 += goff; a.f2 += goff;
+    a.m1 += blockIdx.z * H; a.m2 += blockIdx.z * H;
+    a.out += blockIdx.z * (H * FP);
+    if constexpr (SAVE) { a.t2n += goff * FP; a.t2pos += goff * FP; a.lse += goff; a.q += goff; }
     const float *f2b = a.f2 + b * N * (int64_t)H;
     const bool vec = (N & 3) == 0;
     const float maskf = (!NARROW || m < FP) ? 1.f : 0.f;
@@ -191,6 +198,7 @@ struct BnfBwdArgs {
     float *dX, *dA, *df2, *ws;
     float slope;
     int accumulate;             // dX, dA: add to what is there (a later group of heads of the same step)
+    int64_t nodes, pairs;       // B * N, B * N * N: group g (blockIdx.z) reads G, stats, f2 and writes dX, dA, df2, ws at + g * its size
 };
 
 // Block (b, 64 sources): wave w owns sources 16*w .. 16*w+15, all heads, and walks all destinations.
@@ -211,6 +219,13 @@ __global__ __launch_bounds__(256) void bnf_attn_bwd_kernel(BnfBwdArgs a) {
     const int j0 = blockIdx.y * 64 + wave * 16;
     const int jcol = min(j0 + m, N - 1);
     const bool jok = j0 + m < N;
+    {
+        const int64_t g = blockIdx.z;
+        a.G += g * a.nodes * W; a.stats += g * a.nodes * (3 * H); a.f2 += g * a.nodes * H;
+        a.m1 += g * H; a.m2 += g * H;
+        a.dX += g * a.nodes * FP; a.dA += g * a.pairs; a.df2 += g * a.nodes * H;
+        a.ws += g * (int64_t)gridDim.x * gridDim.y * (2 * H);
+    }
     const float maskf = (!NARROW || m < FP) ? 1.f : 0.f;
     const int mcl = (!NARROW || m < FP) ? m : 0;
 
@@ -344,10 +359,22 @@ __global__ __launch_bounds__(256) void bnf_attn_bwd_kernel(BnfBwdArgs a) {
 }
 
 __global__ void bnf_dm_reduce_kernel(const float *ws, int nblocks, int width, float *out) {
+    ws += (int64_t)blockIdx.y * nblocks * width;              // a group of heads per blockIdx.y
+    out += blockIdx.y * width;
     const int c = blockIdx.x * kSumCols + threadIdx.x;
     const bool ok = c < width;
     const float t = block_column_sum(nblocks, [&](int r) { return ok ? ws[(int64_t)r * width + c] : 0.f; });
     if (ok && threadIdx.y == 0) out[c] = t;
+}
+
+// dst[e] (+)= sum over groups of part[g][e], in group order
+__global__ __launch_bounds__(256) void bnf_group_sum_kernel(const float *part, int groups, int64_t count, int accumulate, float *dst) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < count; e += stride) {
+        float t = accumulate ? dst[e] : 0.f;
+        for (int g = 0; g < groups; ++g) t += part[g * count + e];
+        dst[e] = t;
+    }
 }
 
 #define GATMI_BNF_SHAPES(X) X(4, 1) X(4, 2) X(8, 1) X(8, 2) X(16, 1) X(16, 2) X(32, 1) X(32, 2) X(64, 1) X(64, 2)
@@ -367,20 +394,21 @@ static int bnf_check(int64_t B, int32_t N, int32_t H, int32_t fp, const char *na
 extern "C" int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
                                   const float *X, const float *A, const float *f1, const float *f2,
                                   const float *m1, const float *m2, float slope,
-                                  float *out, int64_t ld_out, float *t2n, float *t2pos, float *lse, float *q, void *stream) {
+                                  float *out, int64_t ld_out, float *t2n, float *t2pos, float *lse, float *q, int32_t groups, void *stream) {
     int rc = bnf_check(B, N, H, fp, "bnf_attn_fwd");
     if (rc) return rc;
+    GATMI_REQUIRE(groups >= 1 && groups <= 1024, GATMI_EINVAL, "bnf_attn_fwd: groups must be 1..1024");
     if (B == 0 || N == 0) return GATMI_OK;
     GATMI_REQUIRE(X && A && f1 && f2 && m1 && m2 && out, GATMI_EINVAL, "bnf_attn_fwd: null pointer");
-    if (ld_out == 0) ld_out = (int64_t)H * fp;
-    GATMI_REQUIRE(ld_out >= (int64_t)H * fp, GATMI_EINVAL, "bnf_attn_fwd: ld_out %lld is less than the %d floats of a row", (long long)ld_out, H * fp);
+    if (ld_out == 0) ld_out = (int64_t)groups * H * fp;
+    GATMI_REQUIRE(ld_out >= (int64_t)groups * H * fp, GATMI_EINVAL, "bnf_attn_fwd: ld_out %lld is less than the %d floats of a row", (long long)ld_out, groups * H * fp);
     const bool save = t2n || t2pos || lse || q;
     GATMI_REQUIRE(!save || (t2n && t2pos && lse && q), GATMI_EINVAL, "bnf_attn_fwd: t2n, t2pos, lse, q must be given together");
     GATMI_REQUIRE_ALIGNED(X); GATMI_REQUIRE_ALIGNED(A);
     BnfFwdArgs a;
     a.N = N; a.X = X; a.A = A; a.f1 = f1; a.f2 = f2; a.m1 = m1; a.m2 = m2;
-    a.out = out; a.t2n = t2n; a.t2pos = t2pos; a.lse = lse; a.q = q; a.slope = slope; a.ld_out = ld_out;
-    const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64));
+    a.out = out; a.t2n = t2n; a.t2pos = t2pos; a.lse = lse; a.q = q; a.slope = slope; a.ld_out = ld_out; a.nodes = B * N;
+    const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64), (unsigned)groups);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X_(ff, hh)                                                                                  \
     if (fp == ff && H == hh) {                                                                      \
@@ -394,31 +422,45 @@ extern "C" int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
     return fail(GATMI_EUNSUPPORTED, "bnf_attn_fwd: no kernel for fp=%d H=%d", fp, H);
 }
 
-extern "C" size_t gatmi_bnf_attn_bwd_ws_floats(int64_t B, int32_t N, int32_t H) {
-    return (size_t)B * (size_t)((N + 63) / 64) * (size_t)(2 * H);
+extern "C" size_t gatmi_bnf_attn_bwd_ws_floats(int64_t B, int32_t N, int32_t H, int32_t fp, int32_t groups) {
+    const size_t dm = (size_t)B * (size_t)((N + 63) / 64) * (size_t)(2 * H) * (size_t)groups;
+    // several groups in one launch: every group's share of dX and dA, summed afterwards
+    return dm + (groups > 1 ? (size_t)groups * ((size_t)B * N * fp + (size_t)B * N * N) : 0);
 }
 
 extern "C" int gatmi_bnf_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t fp,
                                   const float *G, const float *stats, const float *X, const float *A,
                                   const float *f2, const float *m1, const float *m2, float slope,
-                                  float *dX, float *dA, int accumulate, float *df2, float *dm, float *ws, void *stream) {
+                                  float *dX, float *dA, int accumulate, float *df2, float *dm, float *ws, int32_t groups, void *stream) {
     int rc = bnf_check(B, N, H, fp, "bnf_attn_bwd");
     if (rc) return rc;
+    GATMI_REQUIRE(groups >= 1 && groups <= 1024, GATMI_EINVAL, "bnf_attn_bwd: groups must be 1..1024");
     if (B == 0 || N == 0) return GATMI_OK;
     GATMI_REQUIRE(G && stats && X && A && f2 && m1 && m2 && dX && dA && df2 && dm && ws, GATMI_EINVAL, "bnf_attn_bwd: null pointer");
     GATMI_REQUIRE_ALIGNED(G);
     BnfBwdArgs a;
     a.N = N; a.G = G; a.stats = stats; a.X = X; a.A = A; a.f2 = f2; a.m1 = m1; a.m2 = m2;
     a.dX = dX; a.dA = dA; a.df2 = df2; a.ws = ws; a.slope = slope; a.accumulate = accumulate;
-    const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64));
+    a.nodes = B * N; a.pairs = B * N * (int64_t)N;
+    const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64), (unsigned)groups);
+    const int nblocks = (int)(grid.x * grid.y);
+    float *part = ws + (size_t)nblocks * (2 * H) * groups;        // [groups][dX | ...] then [groups][dA]
+    if (groups > 1) {
+        GATMI_REQUIRE_ALIGNED(ws);
+        a.dX = part; a.dA = part + (size_t)groups * a.nodes * fp; a.accumulate = 0;
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X_(ff, hh)                                                                         \
     if (fp == ff && H == hh) {                                                             \
         hipLaunchKernelGGL((bnf_attn_bwd_kernel<ff, hh>), grid, dim3(256), 0, st, a);       \
         GATMI_LAUNCH_CHECK("bnf_attn_bwd");                                                \
-        const int nblocks = (int)(grid.x * grid.y);                                        \
-        hipLaunchKernelGGL(bnf_dm_reduce_kernel, dim3(1), dim3(kSumCols, kSumRows), 0, st, ws, nblocks, 2 * hh, dm); \
+        hipLaunchKernelGGL(bnf_dm_reduce_kernel, dim3(1, groups), dim3(kSumCols, kSumRows), 0, st, ws, nblocks, 2 * hh, dm); \
         GATMI_LAUNCH_CHECK("bnf_dm_reduce");                                               \
+        if (groups > 1) {                                                                  \
+            hipLaunchKernelGGL(bnf_group_sum_kernel, dim3((unsigned)std::min<int64_t>(2048, (a.nodes * fp + 255) / 256)), dim3(256), 0, st, a.dX, groups, a.nodes * fp, accumulate, dX); \
+            hipLaunchKernelGGL(bnf_group_sum_kernel, dim3((unsigned)std::min<int64_t>(2048, (a.pairs + 255) / 256)), dim3(256), 0, st, a.dA, groups, a.pairs, accumulate, dA); \
+            GATMI_LAUNCH_CHECK("bnf_group_sum");                                           \
+        }                                                                                  \
         return GATMI_OK;                                                                   \
     }
     GATMI_BNF_SHAPES(X_)

@@ -592,15 +592,26 @@ def dense_gat_layer(x, W, a1, a2, b1, b2, bias, bias_mat, cfg, W_res=None, b_res
     return DenseGATLayerFn.apply(x, W, a1, a2, b1, b2, bias, W_res, b_res, bias_mat, cfg)
 
 
+def _bnf_head_sets(H):
+    """The kernels sweep two heads per block: (first head, heads per group, groups) for the pairs, which share one
+    launch, and for a last single head."""
+    sets = []
+    if H // 2:
+        sets.append((0, 2, H // 2))
+    if H % 2:
+        sets.append((H - 1, 1, 1))
+    return sets
+
+
 class BnfAggregateFn(torch.autograd.Function):
     """Inner step of the reference's attn_e2v_BNF_V2 (utils/layers.py:173-179, coefficients from
     attn_v2e_BNF_V2 :229-237) for H heads sharing x and the weighted adjacency:
         out[b,i,h,:] = sum_j (m2_h [A_ij>0] + A_ij) (m1_h + softmax_j LeakyReLU(f1_i + f2_j)) x[b,j,:]
     x [B,N,F], net_mat [B,N,N], W [F,H,Dz], a1,a2 [H,Dz], b1,b2,m1,m2 [H]  ->  [B,N,H,F].
-    The kernels sweep two heads per launch; the groups of one step are issued from this one autograd node (slices of
-    the variables taken per group outside would each be a node of their own, with a zero-filled full-size gradient and
-    an accumulation per slice): every group's output lands in its share of the same rows, and the gradients of x and
-    of the adjacency are added up by the kernels."""
+    All heads of a step are issued from this one autograd node (slices of the variables taken per pair of heads outside
+    would each be a node of their own, with a zero-filled full-size gradient and an accumulation per slice), and the
+    pairs of heads share one launch of the attention kernels: at the reference's batch of 50 a launch for two heads
+    is 200 blocks, less than one per compute unit."""
 
     @staticmethod
     def forward(ctx, x, net_mat, W, a1, a2, b1, b2, m1, m2, slope):
@@ -609,87 +620,84 @@ class BnfAggregateFn(torch.autograd.Function):
         H, Dz = a1.shape
         if F > 64:
             raise ValueError("BnfAggregateFn: feature width %d > 64" % F)
-        fp = padded_width(F)
+        fp, dp = padded_width(F), padded_width(Dz)
+        make_cfg(1, Dz, "identity", "concat")                              # the width check of the projection kernels
         n = B * N
         st = _lib.current_stream()
         xp = _pad_last(_f32(x).reshape(n, F), F, fp)
         A = _f32(net_mat).contiguous()
-        Wfull = W.reshape(F, H, Dz)
-        if fp != F:
-            Wfull = torch.zeros((fp, H, Dz), dtype=torch.float32, device=x.device)
-            Wfull[:F] = W.reshape(F, H, Dz)
+        Wp = W.reshape(F, H, Dz)
+        if fp != F or dp != Dz:
+            Wp = torch.zeros((fp, H, dp), dtype=torch.float32, device=x.device)
+            Wp[:F, :, :Dz] = W.reshape(F, H, Dz)
+        a1p, a2p = _pad_last(a1.reshape(H, Dz), Dz, dp), _pad_last(a2.reshape(H, Dz), Dz, dp)
+        b1c, b2c = b1.reshape(H).contiguous(), b2.reshape(H).contiguous()
         m1c, m2c = m1.reshape(H).contiguous(), m2.reshape(H).contiguous()
         out = _new((n, H * fp), x)
         need_grad = any(ctx.needs_input_grad)
-        groups = []
-        for h0 in range(0, H, 2):
-            s = slice(h0, min(h0 + 2, H))
-            hg = s.stop - s.start
-            cfg = make_cfg(hg, Dz, "identity", "concat", slope=slope)
-            Wp, a1p, a2p, _, Z, f1, f2, _ = _project(xp, Wfull[:, s], a1[s], a2[s], b1[s], b2[s], cfg)
+        saved = []
+        for h0, hg, groups in _bnf_head_sets(H):
+            hd = hg * dp
+            # every group's projection weights as one contiguous [fp, hg * dp] block
+            Wg = Wp[:, h0:h0 + groups * hg].reshape(fp, groups, hd).transpose(0, 1).contiguous()
+            Z, f1, f2 = _new((groups, n, hd), x), _new((groups, n, hg), x), _new((groups, n, hg), x)
+            for gi in range(groups):
+                h = h0 + gi * hg
+                _lib.call("gatmi_proj_fwd", ptr(xp), n, fp, fp, ptr(Wg[gi]), ptr(a1p[h:]), ptr(a2p[h:]), ptr(b1c[h:]), ptr(b2c[h:]),
+                          hg, dp, ptr(Z[gi]), None, 0, ptr(f1[gi]), ptr(f2[gi]), None, None, None, 1.0, 0, st)
             t2n = t2pos = lse = q = None
             if need_grad:
-                t2n, t2pos = _new((n, hg * fp), x), _new((n, hg * fp), x)
-                lse, q = _new((n, hg), x), _new((n, hg), x)
-            _lib.call("gatmi_bnf_attn_fwd", B, N, hg, fp, ptr(xp), ptr(A), ptr(f1), ptr(f2), ptr(m1c[s]), ptr(m2c[s]), slope,
-                      ptr(out[:, h0 * fp:]), H * fp, ptr(t2n), ptr(t2pos), ptr(lse), ptr(q), st)
-            groups.append((cfg, [Wp, a1p, a2p, Z, f1, f2, t2n, t2pos, lse, q]))
+                t2n, t2pos = _new((groups, n, hg * fp), x), _new((groups, n, hg * fp), x)
+                lse, q = _new((groups, n, hg), x), _new((groups, n, hg), x)
+            _lib.call("gatmi_bnf_attn_fwd", B, N, hg, fp, ptr(xp), ptr(A), ptr(f1), ptr(f2), ptr(m1c[h0:]), ptr(m2c[h0:]), slope,
+                      ptr(out[:, h0 * fp:]), H * fp, ptr(t2n), ptr(t2pos), ptr(lse), ptr(q), groups, st)
+            saved += [Wg, Z, f1, f2, t2n, t2pos, lse, q]
         if need_grad:
-            ctx.dims, ctx.slope, ctx.cfgs = (B, N, F, H, Dz, fp), slope, [c for c, _ in groups]
-            ctx.save_for_backward(xp, A, m1c, m2c, *[t for _, ts in groups for t in ts])
+            ctx.dims, ctx.slope = (B, N, F, H, Dz, fp, dp), slope
+            ctx.save_for_backward(xp, A, m1c, m2c, a1p, a2p, *saved)
         return out.reshape(B, N, H, fp)[..., :F]
 
     @staticmethod
     def backward(ctx, dout):
-        xp, A, m1c, m2c = ctx.saved_tensors[:4]
-        per_group = ctx.saved_tensors[4:]
-        B, N, F, H, Dz, fp = ctx.dims
+        xp, A, m1c, m2c, a1p, a2p = ctx.saved_tensors[:6]
+        per_set = ctx.saved_tensors[6:]
+        B, N, F, H, Dz, fp, dp = ctx.dims
         slope = ctx.slope
         n = B * N
         st = _lib.current_stream()
-        n_groups = len(ctx.cfgs)
-        G_all = _pad_last(dout.reshape(n, H, F), F, fp)                     # [n, H, fp]
-        if n_groups > 1 and H % 2 == 0:
-            G_all = G_all.reshape(n, n_groups, 2 * fp).transpose(0, 1).contiguous()      # every group's rows contiguous
-        dx = _new((n, fp), xp)
-        dA = _new((B, N, N), xp)
-        dp = ctx.cfgs[0].dp
+        G_all = _pad_last(_f32(dout).reshape(n, H, F), F, fp)                # [n, H, fp]
+        dx, dA = _new((n, fp), xp), _new((B, N, N), xp)
         dW = _new((fp, H, dp), xp)
         da1, da2 = _new((H, dp), xp), _new((H, dp), xp)
         db1, db2 = _new((H,), xp), _new((H,), xp)
         dm = _new((2, H), xp)
-        for gi, cfg in enumerate(ctx.cfgs):
-            Wp, a1p, a2p, Z, f1, f2, t2n, t2pos, lse, q = per_group[10 * gi:10 * gi + 10]
-            h0, hg = 2 * gi, cfg.H
-            if n_groups == 1:
-                G = G_all.reshape(n, hg * fp)
-            elif H % 2 == 0:
-                G = G_all[gi]
-            else:
-                G = G_all[:, h0:h0 + hg].reshape(n, hg * fp).contiguous()
-            g = _new((n, hg * fp), xp)
-            stats = _new((n, 3 * hg), xp)
-            df1 = _new((n, hg), xp)
+        for si, (h0, hg, groups) in enumerate(_bnf_head_sets(H)):
+            Wg, Z, f1, f2, t2n, t2pos, lse, q = per_set[8 * si:8 * si + 8]
+            hd, heads = hg * dp, groups * hg
+            # every group's rows of the incoming gradient contiguous: [groups, n, hg * fp]
+            G = G_all[:, h0:h0 + heads].reshape(n, groups, hg * fp).transpose(0, 1).contiguous()
+            g, stats, df1 = _new((groups, n, hg * fp), xp), _new((groups, n, 3 * hg), xp), _new((groups, n, hg), xp)
             ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(hg, fp),), xp)
-            _lib.call("gatmi_gat_bwd_node", n, hg, fp, ptr(G), None, ptr(t2n), ptr(t2pos), ptr(q), ptr(f1), ptr(lse), None,
-                      _lib.ACT_IDENTITY, _lib.REDUCE_CONCAT, slope, ptr(g), hg * fp, None, 0, ptr(stats), 3 * hg, ptr(df1), None, ptr(ws), st)
-            df2 = _new((n, hg), xp)
-            dmg = _new((2 * hg,), xp)
-            ws2 = _new((max(1, _lib.lib.gatmi_bnf_attn_bwd_ws_floats(B, N, hg)),), xp)
+            for gi in range(groups):
+                _lib.call("gatmi_gat_bwd_node", n, hg, fp, ptr(G[gi]), None, ptr(t2n[gi]), ptr(t2pos[gi]), ptr(q[gi]), ptr(f1[gi]), ptr(lse[gi]), None,
+                          _lib.ACT_IDENTITY, _lib.REDUCE_CONCAT, slope, ptr(g[gi]), hg * fp, None, 0, ptr(stats[gi]), 3 * hg, ptr(df1[gi]), None, ptr(ws), st)
+            df2 = _new((groups, n, hg), xp)
+            dmg = _new((groups, 2, hg), xp)
+            ws2 = _new((max(1, _lib.lib.gatmi_bnf_attn_bwd_ws_floats(B, N, hg, fp, groups)),), xp)
             _lib.call("gatmi_bnf_attn_bwd", B, N, hg, fp, ptr(g), ptr(stats), ptr(xp), ptr(A), ptr(f2), ptr(m1c[h0:]), ptr(m2c[h0:]), slope,
-                      ptr(dx), ptr(dA), int(gi > 0), ptr(df2), ptr(dmg), ptr(ws2), st)
-            dm[:, h0:h0 + hg] = dmg.reshape(2, hg)
+                      ptr(dx), ptr(dA), int(si > 0), ptr(df2), ptr(dmg), ptr(ws2), groups, st)
+            dm[:, h0:h0 + heads] = dmg.transpose(0, 1).reshape(2, heads)
             # the projection only feeds the logit halves: dZ = df1 a1 + df2 a2
-            hd = hg * dp
-            dZ = torch.zeros((n, hd), dtype=torch.float32, device=xp.device)
-            _lib.call("gatmi_gat_bwd_finalize", n, hg, dp, ptr(df1), ptr(df2), ptr(a1p), ptr(a2p), ptr(dZ), st)
+            dZ = torch.zeros((groups, n, hd), dtype=torch.float32, device=xp.device)
+            dWg = _new((groups, fp, hd), xp)
             wsp = _new((_lib.lib.gatmi_proj_bwd_ws_floats(fp, hg, dp),), xp)
-            dWg = dW if n_groups == 1 else _new((fp, hd), xp)
-            _lib.call("gatmi_proj_bwd_params", ptr(xp), n, fp, fp, ptr(dZ), ptr(Z), ptr(df1), ptr(df2), hg, dp,
-                      ptr(dWg), ptr(da1[h0:]), ptr(da2[h0:]), ptr(db1[h0:]), ptr(db2[h0:]), ptr(wsp), 1.0, 0, st)
-            if n_groups > 1:
-                dW[:, h0:h0 + hg] = dWg.reshape(fp, hg, dp)
-            _lib.call("gatmi_proj_bwd_input", ptr(dZ), n, fp, ptr(Wp), hg, dp, ptr(dx), fp, 1, 1.0, 0, st)
+            for gi in range(groups):
+                h = h0 + gi * hg
+                _lib.call("gatmi_gat_bwd_finalize", n, hg, dp, ptr(df1[gi]), ptr(df2[gi]), ptr(a1p[h:]), ptr(a2p[h:]), ptr(dZ[gi]), st)
+                _lib.call("gatmi_proj_bwd_params", ptr(xp), n, fp, fp, ptr(dZ[gi]), ptr(Z[gi]), ptr(df1[gi]), ptr(df2[gi]), hg, dp,
+                          ptr(dWg[gi]), ptr(da1[h:]), ptr(da2[h:]), ptr(db1[h:]), ptr(db2[h:]), ptr(wsp), 1.0, 0, st)
+                _lib.call("gatmi_proj_bwd_input", ptr(dZ[gi]), n, fp, ptr(Wg[gi]), hg, dp, ptr(dx), fp, 1, 1.0, 0, st)
+            dW[:, h0:h0 + heads] = dWg.reshape(groups, fp, hg, dp).transpose(0, 1).reshape(fp, heads, dp)
         return (dx[:, :F].reshape(B, N, F), dA, dW[:F, :, :Dz], da1[:, :Dz], da2[:, :Dz], db1, db2, dm[0], dm[1], None)
 
 
