@@ -1077,6 +1077,22 @@ extern "C" int gatmi_linear_bwd_params(const float *X, int64_t n, int32_t f_in, 
     return GATMI_OK;
 }
 
+extern "C" size_t gatmi_column_sums_ws_floats(int64_t n, int32_t w) {
+    return n <= 0 || w <= 0 ? 1 : (size_t)column_sum_blocks(n) * (size_t)w;
+}
+
+extern "C" int gatmi_column_sums(const float *Y, int64_t n, int32_t w, int64_t ld, float *out, float *ws, void *stream) {
+    GATMI_REQUIRE(n >= 0 && w > 0 && ld >= w, GATMI_EINVAL, "column_sums: bad dims");
+    GATMI_REQUIRE(Y && out && ws, GATMI_EINVAL, "column_sums: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned nb = column_sum_blocks(n);
+    hipLaunchKernelGGL(column_partial_kernel, dim3(nb, (unsigned)((w + 63) / 64)), dim3(256), 0, st, Y, n, w, ld, ws);
+    GATMI_LAUNCH_CHECK("column_partial");
+    hipLaunchKernelGGL(column_total_kernel, dim3((unsigned)((w + kSumCols - 1) / kSumCols)), dim3(kSumCols, kSumRows), 0, st, ws, (int)nb, w, out);
+    GATMI_LAUNCH_CHECK("column_total");
+    return GATMI_OK;
+}
+
 extern "C" int gatmi_proj_bwd_input(const float *dWh, int64_t n, int32_t f_in, const float *W,
                                     int32_t H, int32_t dp, float *dX, int64_t lddx, int accumulate,
                                     float in_keep, uint64_t seed, void *stream) {

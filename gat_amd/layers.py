@@ -396,7 +396,8 @@ class AttnE2VBNFV2(nn.Module):
         seq_out, outs = seq, []
         for rep in range(self.reps):
             agg = self.att[rep](seq_out, net_mat)                                        # [B,N,H,F]   layers.py:174-179
-            heads = self._act(torch.einsum("bnhf,hfo->bnho", agg, self.head_w[rep]) + self.head_b[rep])   # :180
+            heads = torch.einsum("bnhf,hfo->bnho", agg, self.head_w[rep])
+            heads = self._act(ops.add_row_bias(heads.flatten(2), self.head_b[rep].reshape(-1))).unflatten(2, self.head_b[rep].shape)   # :180
             merged = self._act(_linear(self.merge[rep], heads.flatten(2)))              # :182-183
             if self.residual:
                 seq_out = merged + _linear(self.res[rep], seq_out)                      # :185-189

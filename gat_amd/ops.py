@@ -755,6 +755,39 @@ def tall_linear(x, weight, bias=None):
     return TallLinearFn.apply(x.reshape(n, x.shape[-1]), weight, bias).reshape(*lead, weight.shape[0])
 
 
+class RowBiasFn(torch.autograd.Function):
+    """y = x + b for x [n, w]: the bias of a width-1 convolution (utils/layers.py:180); its gradient, the column
+    sums over the n rows, comes from gatmi_column_sums."""
+
+    @staticmethod
+    def forward(ctx, x, b):
+        _require_cuda(x, b)
+        return x + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        db = None
+        if ctx.needs_input_grad[1]:
+            d = _f32(dy)
+            if d.stride(1) != 1:
+                d = d.contiguous()
+            n, w = d.shape
+            db = _new((w,), d)
+            ws = _new((_lib.lib.gatmi_column_sums_ws_floats(n, w),), d)
+            _lib.call("gatmi_column_sums", ptr(d), n, w, d.stride(0), ptr(db), ptr(ws), _lib.current_stream())
+        return dy, db
+
+
+def add_row_bias(x, bias):
+    """x [..., w] + bias [w] with the bias gradient from the library's fixed-order column sums (many rows, fp32, GPU);
+    torch's own broadcast add otherwise."""
+    w = x.shape[-1]
+    n = x.numel() // max(1, w)
+    if not x.is_cuda or x.dtype != torch.float32 or n < TALL_LINEAR_ROWS or not torch.is_grad_enabled() or not x.is_contiguous():
+        return x + bias
+    return RowBiasFn.apply(x.reshape(n, w), bias.reshape(w)).reshape(x.shape)
+
+
 class InnerProductDecoderFn(torch.autograd.Function):
     """utils/layers.py:307-313: act(dropout(z) . dropout(z)^T) per graph, z [B,N,F] -> [B,N,N]."""
 

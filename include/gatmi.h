@@ -175,6 +175,11 @@ size_t gatmi_linear_bwd_ws_floats(int64_t n, int32_t f_in, int32_t w);
 int gatmi_linear_bwd_params(const float *X, int64_t n, int32_t f_in, int64_t ldx, const float *dY, int32_t w,
                             float *dW, float *db, float *ws, void *stream);
 
+/* out [w] = column sums of Y [n, w] (row stride ld floats): the gradient of a bias added to every node row
+ * (the bias of tf.layers.conv1d, utils/layers.py:180), in a fixed order.  ws: gatmi_column_sums_ws_floats(n, w). */
+size_t gatmi_column_sums_ws_floats(int64_t n, int32_t w);
+int gatmi_column_sums(const float *Y, int64_t n, int32_t w, int64_t ld, float *out, float *ws, void *stream);
+
 /* The projection for SPARSE node features: X [n, f_in] in CSR (xrowptr [n+1], xcol, xval in DEVICE
  * memory), as the sparse tuple of preprocess_features (utils/process.py:155-162, the second return
  * value) describes it; Cora's features are 98.7 % zeros.  Wh = X . W summed over stored entries

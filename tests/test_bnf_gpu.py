@@ -138,3 +138,19 @@ def test_tall_linear_matches_the_plain_dense_layer(n, f_in, w, strided):
     y2 = ops.tall_linear(xs, W)
     y2.backward(dy.to(dev, torch.float32))
     assert ops.tall_linear(xs[:100], W, b).grad_fn is not None and "TallLinearFn" not in type(ops.tall_linear(xs[:100], W, b).grad_fn).__name__
+
+
+@pytest.mark.parametrize("shape", [(50, 246, 384), (3, 1000, 7), (2048, 64)])
+def test_row_bias_gradient_is_the_column_sum(shape):
+    from gat_amd import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(shape[-1])
+    x64, b64, dy = torch.tensor(rng.normal(0, 1, shape), requires_grad=True), torch.tensor(rng.normal(0, 1, shape[-1]), requires_grad=True), torch.tensor(rng.normal(0, 1, shape))
+    ((x64 + b64) * dy).sum().backward()
+    x = x64.detach().to(dev, torch.float32).requires_grad_(True)
+    b = b64.detach().to(dev, torch.float32).requires_grad_(True)
+    y = ops.add_row_bias(x, b)
+    assert torch.equal(y, x + b)
+    y.backward(dy.to(dev, torch.float32))
+    assert_close(b.grad.cpu().numpy(), b64.grad.numpy(), what="row bias db")
+    assert torch.equal(x.grad, dy.to(dev, torch.float32))
