@@ -7,7 +7,8 @@ graph's kernels run with arguments of unrelated eager launches, outputs keep the
 replay reports no error.  It takes no code of this package to see it (benchmarks/micro/graph_replay_min.py shows it with
 plain torch operators; a replay stream of its own does not help).  With DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 the runtime
 builds the packets on every replay and the results stay right (the same reproducer, 20 000 launches in between); a
-replayed training step of the 50 x 90-node autoencoder costs 4.4 ms that way against 4.1 ms, and 12.3 ms eager.
+replayed training step of a 50 x 90-node autoencoder cost 4.4 ms that way against 4.1 ms, and 12.3 ms eager,
+when the switch was introduced.
 
 The runtime reads the switch once, at the process's first HIP call, so it is set here, when the package is imported,
 unless the environment already holds a value (set it to 1 to keep the runtime's default).  A process that has already
