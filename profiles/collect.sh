@@ -1,13 +1,13 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of one round on the GPU box:  bash profiles/collect.sh <tag> [part ...]
-# Parts (default: all): bench  stats  pmc_sparse  stats_dense  pmc_dense  pmc_bnf
+# Parts (default: all): bench  stats  pmc_sparse  stats_dense  pmc_dense  pmc_bnf  stats_bnf
 # Everything lands in gpurun_out/<tag>_prof/; profiles/summarize.py turns it into the files kept under profiles/.
 # gpurun merges what a run wrote into the local gpurun_out/ and deletes nothing there: remove the local
 # gpurun_out/<tag>_prof before collecting a part again, or the summaries mix two builds.
 # Counter passes run on their own (no tracing beside --pmc) and each within the per-block counter limits.
 set -u
 TAG=${1:?tag}; shift
-PARTS=${*:-bench stats pmc_sparse stats_dense pmc_dense pmc_bnf}
+PARTS=${*:-bench stats pmc_sparse stats_dense pmc_dense pmc_bnf stats_bnf}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/${TAG}_prof
 mkdir -p "$OUT"
@@ -64,6 +64,15 @@ for part in $PARTS; do
         done ;;
     pmc_bnf)
         pmc bnf_sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- "$ROOT/benchmarks/bench_bnf.py" || exit 1 ;;
+    stats_bnf)
+        echo "[collect] bench_bnf.py, and kernel stats of the autoencoder step at the sizes of BNF_AE.py"
+        timeout -k 10 200 python3 "$ROOT/benchmarks/bench_bnf.py" > "$OUT/bench_bnf.json" 2> "$OUT/bench_bnf.err" || exit 1
+        AE="$ROOT/examples/train_bnf_ae_like.py --quiet --nodes 246 --hid 64 --heads 6 --cam 256"
+        timeout -k 10 200 python3 $AE --steps 100 > "$OUT/bnf_autoencoder.txt" 2>> "$OUT/bench_bnf.err" || exit 1
+        timeout -k 10 200 python3 $AE --steps 100 --replay >> "$OUT/bnf_autoencoder.txt" 2>> "$OUT/bench_bnf.err" || exit 1
+        rm -rf "$OUT/stats_bnf_ae"
+        timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_bnf_ae" --output-format csv -- python3 $AE --steps 52 --replay > "$OUT/stats_bnf_ae.log" 2>&1 || exit 1
+        find "$OUT/stats_bnf_ae" -name "*kernel_trace.csv" -delete ;;
     *) echo "unknown part $part"; exit 2 ;;
     esac
 done

@@ -4,6 +4,7 @@
     <tag>_bench_n1_kernel_stats.csv        rocprofv3 --kernel-trace --stats summary of bench.py
     <tag>_bench_n1_pmc_summary.txt         mean counter values per kernel (FETCH_SIZE, WRITE_SIZE, TCC, SQ passes)
     <tag>_bench_dense_<path>_kernel_stats.csv, <tag>_dense_pmc_summary.txt, <tag>_bnf_pmc_summary.txt
+    <tag>_bench_bnf.json, <tag>_bnf_autoencoder.txt, <tag>_bnf_autoencoder_kernel_stats.csv   brain-network step and autoencoder
     traffic.json                           HBM-side bytes per launch of the three sparse kernels, with the kernel symbols
                                            they were counted on (bench.py attaches a figure only to the same symbol)
 usage: python profiles/summarize.py <tag>"""
@@ -81,7 +82,8 @@ def main():
     copy_stats(os.path.join(src, "stats_bench"), os.path.join(HERE, tag + "_bench_n1_kernel_stats.csv"))
     for mp in ("lists", "dense", "csr", "prebuilt", "lists_drop", "prebuilt_drop"):
         copy_stats(os.path.join(src, "stats_dense_" + mp), os.path.join(HERE, "%s_bench_dense_%s_kernel_stats.csv" % (tag, mp)))
-    for name in ("bench_dense.jsonl", "bench_two_layer.jsonl"):
+    copy_stats(os.path.join(src, "stats_bnf_ae"), os.path.join(HERE, tag + "_bnf_autoencoder_kernel_stats.csv"))
+    for name in ("bench_dense.jsonl", "bench_two_layer.jsonl", "bench_bnf.json", "bnf_autoencoder.txt"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(HERE, "%s_%s" % (tag, name)))
     sparse = counters([os.path.join(src, "pmc_" + n) for n in ("fetch", "write", "tcc", "sq")])
