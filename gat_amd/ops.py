@@ -604,14 +604,17 @@ def _bnf_head_sets(H):
 
 
 class BnfAggregateFn(torch.autograd.Function):
-    """Inner step of the reference's attn_e2v_BNF_V2 (utils/layers.py:173-179, coefficients from
-    attn_v2e_BNF_V2 :229-237) for H heads sharing x and the weighted adjacency:
-        out[b,i,h,:] = sum_j (m2_h [A_ij>0] + A_ij) (m1_h + softmax_j LeakyReLU(f1_i + f2_j)) x[b,j,:]
+    """Inner step of the reference's attn_e2v_BNF_V2 (utils/layers.py:173-179, coefficients from attn_v2e_BNF_V2
+    :229-237) for H heads sharing x and the weighted adjacency:
+        out[b,i,h,:] = sum_j (m2_h [A_ij>0] + A_ij) (m1_h + softmax_j LeakyReLU(f1_ih + f2_jh)) x[b,j,:]
     x [B,N,F], net_mat [B,N,N], W [F,H,Dz], a1,a2 [H,Dz], b1,b2,m1,m2 [H]  ->  [B,N,H,F].
+    The logit halves: seq_fts = conv1d(seq, Dz, 1) (:231, no bias) feeds nothing but f_s = conv1d(seq_fts, 1, 1)
+    (:232-233), so the two width-1 convolutions are applied as one, f_s[., h] = x . (W[:, h, :] a_s[h]) + b_s[h]: an [F]
+    vector per head and half instead of an [n, Dz] table per head, forward and backward.
     All heads of a step are issued from this one autograd node (slices of the variables taken per pair of heads outside
     would each be a node of their own, with a zero-filled full-size gradient and an accumulation per slice), and the
-    pairs of heads share one launch of the attention kernels: at the reference's batch of 50 a launch for two heads
-    is 200 blocks, less than one per compute unit."""
+    pairs of heads share one launch of the attention kernels: at the reference's batch of 50 a launch for two heads is
+    200 blocks, less than one per compute unit."""
 
     @staticmethod
     def forward(ctx, x, net_mat, W, a1, a2, b1, b2, m1, m2, slope):
@@ -620,85 +623,73 @@ class BnfAggregateFn(torch.autograd.Function):
         H, Dz = a1.shape
         if F > 64:
             raise ValueError("BnfAggregateFn: feature width %d > 64" % F)
-        fp, dp = padded_width(F), padded_width(Dz)
-        make_cfg(1, Dz, "identity", "concat")                              # the width check of the projection kernels
+        fp = padded_width(F)
         n = B * N
         st = _lib.current_stream()
-        xp = _pad_last(_f32(x).reshape(n, F), F, fp)
+        x2d = _f32(x).reshape(n, F)
+        xp = _pad_last(x2d, F, fp)
         A = _f32(net_mat).contiguous()
-        Wp = W.reshape(F, H, Dz)
-        if fp != F or dp != Dz:
-            Wp = torch.zeros((fp, H, dp), dtype=torch.float32, device=x.device)
-            Wp[:F, :, :Dz] = W.reshape(F, H, Dz)
-        a1p, a2p = _pad_last(a1.reshape(H, Dz), Dz, dp), _pad_last(a2.reshape(H, Dz), Dz, dp)
-        b1c, b2c = b1.reshape(H).contiguous(), b2.reshape(H).contiguous()
+        a12 = torch.stack([a1.reshape(H, Dz), a2.reshape(H, Dz)])            # [2, H, Dz]
+        Wc = torch.einsum("fhd,shd->shf", W.reshape(F, H, Dz), a12).reshape(2 * H, F)
+        f12 = torch.addmm(torch.cat([b1.reshape(H), b2.reshape(H)]), x2d, Wc.t()).reshape(n, 2, H)
         m1c, m2c = m1.reshape(H).contiguous(), m2.reshape(H).contiguous()
         out = _new((n, H * fp), x)
         need_grad = any(ctx.needs_input_grad)
         saved = []
         for h0, hg, groups in _bnf_head_sets(H):
-            hd = hg * dp
-            # every group's projection weights as one contiguous [fp, hg * dp] block
-            Wg = Wp[:, h0:h0 + groups * hg].reshape(fp, groups, hd).transpose(0, 1).contiguous()
-            Z, f1, f2 = _new((groups, n, hd), x), _new((groups, n, hg), x), _new((groups, n, hg), x)
-            for gi in range(groups):
-                h = h0 + gi * hg
-                _lib.call("gatmi_proj_fwd", ptr(xp), n, fp, fp, ptr(Wg[gi]), ptr(a1p[h:]), ptr(a2p[h:]), ptr(b1c[h:]), ptr(b2c[h:]),
-                          hg, dp, ptr(Z[gi]), None, 0, ptr(f1[gi]), ptr(f2[gi]), None, None, None, 1.0, 0, st)
+            # [2, groups, n, hg]: every group's f1 rows, then every group's f2 rows
+            f = f12[:, :, h0:h0 + groups * hg].reshape(n, 2, groups, hg).permute(1, 2, 0, 3).contiguous()
             t2n = t2pos = lse = q = None
             if need_grad:
                 t2n, t2pos = _new((groups, n, hg * fp), x), _new((groups, n, hg * fp), x)
                 lse, q = _new((groups, n, hg), x), _new((groups, n, hg), x)
-            _lib.call("gatmi_bnf_attn_fwd", B, N, hg, fp, ptr(xp), ptr(A), ptr(f1), ptr(f2), ptr(m1c[h0:]), ptr(m2c[h0:]), slope,
+            _lib.call("gatmi_bnf_attn_fwd", B, N, hg, fp, ptr(xp), ptr(A), ptr(f[0]), ptr(f[1]), ptr(m1c[h0:]), ptr(m2c[h0:]), slope,
                       ptr(out[:, h0 * fp:]), H * fp, ptr(t2n), ptr(t2pos), ptr(lse), ptr(q), groups, st)
-            saved += [Wg, Z, f1, f2, t2n, t2pos, lse, q]
+            saved += [f, t2n, t2pos, lse, q]
         if need_grad:
-            ctx.dims, ctx.slope = (B, N, F, H, Dz, fp, dp), slope
-            ctx.save_for_backward(xp, A, m1c, m2c, a1p, a2p, *saved)
+            ctx.dims, ctx.slope = (B, N, F, H, fp), slope
+            ctx.save_for_backward(xp, A, m1c, m2c, W, a12, Wc, *saved)
         return out.reshape(B, N, H, fp)[..., :F]
 
     @staticmethod
     def backward(ctx, dout):
-        xp, A, m1c, m2c, a1p, a2p = ctx.saved_tensors[:6]
-        per_set = ctx.saved_tensors[6:]
-        B, N, F, H, Dz, fp, dp = ctx.dims
+        xp, A, m1c, m2c, W, a12, Wc = ctx.saved_tensors[:7]
+        per_set = ctx.saved_tensors[7:]
+        B, N, F, H, fp = ctx.dims
         slope = ctx.slope
         n = B * N
         st = _lib.current_stream()
         G_all = _pad_last(_f32(dout).reshape(n, H, F), F, fp)                # [n, H, fp]
         dx, dA = _new((n, fp), xp), _new((B, N, N), xp)
-        dW = _new((fp, H, dp), xp)
-        da1, da2 = _new((H, dp), xp), _new((H, dp), xp)
-        db1, db2 = _new((H,), xp), _new((H,), xp)
+        df12 = _new((n, 2, H), xp)
         dm = _new((2, H), xp)
         for si, (h0, hg, groups) in enumerate(_bnf_head_sets(H)):
-            Wg, Z, f1, f2, t2n, t2pos, lse, q = per_set[8 * si:8 * si + 8]
-            hd, heads = hg * dp, groups * hg
+            f, t2n, t2pos, lse, q = per_set[5 * si:5 * si + 5]
+            heads = groups * hg
             # every group's rows of the incoming gradient contiguous: [groups, n, hg * fp]
             G = G_all[:, h0:h0 + heads].reshape(n, groups, hg * fp).transpose(0, 1).contiguous()
-            g, stats, df1 = _new((groups, n, hg * fp), xp), _new((groups, n, 3 * hg), xp), _new((groups, n, hg), xp)
+            g, stats = _new((groups, n, hg * fp), xp), _new((groups, n, 3 * hg), xp)
+            df = _new((2, groups, n, hg), xp)                                 # df1 of every group, then df2
             ws = _new((_lib.lib.gatmi_gat_bwd_node_ws_floats(hg, fp),), xp)
             for gi in range(groups):
-                _lib.call("gatmi_gat_bwd_node", n, hg, fp, ptr(G[gi]), None, ptr(t2n[gi]), ptr(t2pos[gi]), ptr(q[gi]), ptr(f1[gi]), ptr(lse[gi]), None,
-                          _lib.ACT_IDENTITY, _lib.REDUCE_CONCAT, slope, ptr(g[gi]), hg * fp, None, 0, ptr(stats[gi]), 3 * hg, ptr(df1[gi]), None, ptr(ws), st)
-            df2 = _new((groups, n, hg), xp)
+                _lib.call("gatmi_gat_bwd_node", n, hg, fp, ptr(G[gi]), None, ptr(t2n[gi]), ptr(t2pos[gi]), ptr(q[gi]), ptr(f[0, gi]), ptr(lse[gi]), None,
+                          _lib.ACT_IDENTITY, _lib.REDUCE_CONCAT, slope, ptr(g[gi]), hg * fp, None, 0, ptr(stats[gi]), 3 * hg, ptr(df[0, gi]), None, ptr(ws), st)
             dmg = _new((groups, 2, hg), xp)
             ws2 = _new((max(1, _lib.lib.gatmi_bnf_attn_bwd_ws_floats(B, N, hg, fp, groups)),), xp)
-            _lib.call("gatmi_bnf_attn_bwd", B, N, hg, fp, ptr(g), ptr(stats), ptr(xp), ptr(A), ptr(f2), ptr(m1c[h0:]), ptr(m2c[h0:]), slope,
-                      ptr(dx), ptr(dA), int(si > 0), ptr(df2), ptr(dmg), ptr(ws2), groups, st)
+            _lib.call("gatmi_bnf_attn_bwd", B, N, hg, fp, ptr(g), ptr(stats), ptr(xp), ptr(A), ptr(f[1]), ptr(m1c[h0:]), ptr(m2c[h0:]), slope,
+                      ptr(dx), ptr(dA), int(si > 0), ptr(df[1]), ptr(dmg), ptr(ws2), groups, st)
             dm[:, h0:h0 + heads] = dmg.transpose(0, 1).reshape(2, heads)
-            # the projection only feeds the logit halves: dZ = df1 a1 + df2 a2
-            dZ = torch.zeros((groups, n, hd), dtype=torch.float32, device=xp.device)
-            dWg = _new((groups, fp, hd), xp)
-            wsp = _new((_lib.lib.gatmi_proj_bwd_ws_floats(fp, hg, dp),), xp)
-            for gi in range(groups):
-                h = h0 + gi * hg
-                _lib.call("gatmi_gat_bwd_finalize", n, hg, dp, ptr(df1[gi]), ptr(df2[gi]), ptr(a1p[h:]), ptr(a2p[h:]), ptr(dZ[gi]), st)
-                _lib.call("gatmi_proj_bwd_params", ptr(xp), n, fp, fp, ptr(dZ[gi]), ptr(Z[gi]), ptr(df1[gi]), ptr(df2[gi]), hg, dp,
-                          ptr(dWg[gi]), ptr(da1[h:]), ptr(da2[h:]), ptr(db1[h:]), ptr(db2[h:]), ptr(wsp), 1.0, 0, st)
-                _lib.call("gatmi_proj_bwd_input", ptr(dZ[gi]), n, fp, ptr(Wg[gi]), hg, dp, ptr(dx), fp, 1, 1.0, 0, st)
-            dW[:, h0:h0 + heads] = dWg.reshape(groups, fp, hg, dp).transpose(0, 1).reshape(fp, heads, dp)
-        return (dx[:, :F].reshape(B, N, F), dA, dW[:F, :, :Dz], da1[:, :Dz], da2[:, :Dz], db1, db2, dm[0], dm[1], None)
+            df12[:, :, h0:h0 + heads] = df.permute(2, 0, 1, 3).reshape(n, 2, heads)
+        # the logit halves: dWc = x^T df12 and the bias sums over the node rows, then the chain rule through Wc = W . a
+        df12 = df12.reshape(n, 2 * H)
+        dWc, db = _new((fp, 2 * H), xp), _new((2 * H,), xp)
+        wsl = _new((_lib.lib.gatmi_linear_bwd_ws_floats(n, fp, 2 * H),), xp)
+        _lib.call("gatmi_linear_bwd_params", ptr(xp), n, fp, fp, ptr(df12), 2 * H, ptr(dWc), ptr(db), ptr(wsl), st)
+        dWc = dWc[:F].reshape(F, 2, H)
+        dW = torch.einsum("fsh,shd->fhd", dWc, a12)
+        da12 = torch.einsum("fhd,fsh->shd", W.reshape(F, H, -1), dWc)
+        dxs = torch.addmm(dx[:, :F], df12, Wc)
+        return dxs.reshape(B, N, F), dA, dW.reshape(W.shape), da12[0], da12[1], db[:H], db[H:], dm[0], dm[1], None
 
 
 def bnf_aggregate(x, net_mat, W, a1, a2, b1, b2, m1, m2, slope=LEAKY_SLOPE):

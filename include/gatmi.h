@@ -497,7 +497,7 @@ int gatmi_scale_by_device_scalar(float *x, int64_t n, const float *scale, void *
  * (stimulate_mag_1 / _2):
  *     out[b,i,h,:] = sum_j (m2[h]*[A_ij > 0] + A_ij) * (m1[h] + softmax_j(LeakyReLU(f1_i + f2_j))) * X[b,j,:]
  *   X [B,N,fp] (fp = feature width padded to 4, 8, 16, 32 or 64; padded columns zero), A [B,N,N],
- *   f1,f2 [B,N,H] (from gatmi_proj_fwd), m1,m2 [H] in DEVICE memory, H = 1 or 2;
+ *   f1,f2 [B,N,H] (the logit halves of :232-233: x . (W a_s) + b_s), m1,m2 [H] in DEVICE memory, H = 1 or 2;
  *   out [B,N,H,fp], rows ld_out floats apart (0 = contiguous); t2n, t2pos [B,N,H,fp], lse, q [B,N,H]: saved for
  *   backward, or all NULL.
  *   groups > 1: one launch for groups x H heads of the same step (the reference runs n_heads of these steps on one
