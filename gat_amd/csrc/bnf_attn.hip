@@ -11,8 +11,9 @@
 // Backward (per source tile, all heads in one wave): D_ij = <G_i, X_j> by MFMA (K = feature
 // width) lands in the C layout; there C, n, w = n (m1 + C) are recomputed, and w^T . G (C layout
 // reused as the A layout of the transpose) accumulates dX_j.  dA_ij = (m1 + C_ij) D_ij is written
-// per tile, df2 / dm1 / dm2 are register sums, df1 comes from the positive-part sums of the
-// forward pass (same identity as in gat_sparse.hip, with c_i = <G_i, T2_i / s_i>).
+// per tile, df2 / dm1 / dm2 are register sums, and df1_i = sum_j dlogit_ij is summed over the 16 sources of a wave
+// with DPP steps, over the waves in LDS and over the source blocks by a small second kernel (c_i = <G_i, T2_i / s_i>
+// comes from a row kernel that runs first).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -30,7 +31,7 @@ constexpr int kBnfBlocksMax = 1 << 20;
 struct BnfFwdArgs {
     int N;
     const float *X, *A, *f1, *f2, *m1, *m2;
-    float *out, *t2n, *t2pos, *lse, *q;
+    float *out, *t2n, *lse;
     float slope;
     int64_t ld_out;             // floats between rows of out (>= groups * H * FP): a call may fill its heads' share of wider rows
     int64_t nodes;              // B * N: group g (blockIdx.z) reads f1, f2 at + g * nodes * H, saves at + g * nodes * H (* FP)
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
     a.f1 += goff; a.f2 += goff;
     a.m1 += blockIdx.z * H; a.m2 += blockIdx.z * H;
     a.out += blockIdx.z * (H * FP);
-    if constexpr (SAVE) { a.t2n += goff * FP; a.t2pos += goff * FP; a.lse += goff; a.q += goff; }
+    if constexpr (SAVE) { a.t2n += goff * FP; a.lse += goff; }
     const float *f2b = a.f2 + b * N * (int64_t)H;
     const bool vec = (N & 3) == 0;
     const float maskf = (!NARROW || m < FP) ? 1.f : 0.f;
@@ -88,18 +89,15 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
         mx[h] = fmaxf(mx[h], __shfl_xor(mx[h], 32, 64));
     }
     // ---- sweep 2 ----------------------------------------------------------------------------------
-    f32x4 accU[NT], accV[NT], acc2[H][NT], acc2p[SAVE ? H : 1][NT];
-    float ssum[H], qsum[H];
+    f32x4 accU[NT], accV[NT], acc2[H][NT];
+    float ssum[H];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) accU[nt] = accV[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-        ssum[h] = qsum[h] = 0.f;
+        ssum[h] = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            acc2[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if constexpr (SAVE) acc2p[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+        for (int nt = 0; nt < NT; ++nt) acc2[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     for (int jc = 0; jc < N; jc += kBnfJC) {
         __syncthreads();
@@ -138,15 +136,10 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
                 for (int h = 0; h < H; ++h) {
                     const float z = f1v[h] + f2s[(jl + 4 * kq + t) * H + h];     // -inf for j >= N => p = 0
                     const float p = exp_neg(leaky(z, a.slope) - mx[h]);
-                    const bool ps = z > 0.f;
                     ssum[h] += p;
-                    qsum[h] += ps ? p : 0.f;
                     const float np_ = (m2v[h] * th + av[t]) * p;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc2[h][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(np_, xr[nt], acc2[h][nt], 0, 0, 0);
-                        if constexpr (SAVE) acc2p[h][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ps ? np_ : 0.f, xr[nt], acc2p[h][nt], 0, 0, 0);
-                    }
+                    for (int nt = 0; nt < NT; ++nt) acc2[h][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(np_, xr[nt], acc2[h][nt], 0, 0, 0);
                 }
             }
         }
@@ -155,7 +148,6 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         ssum[h] += __shfl_xor(ssum[h], 16, 64); ssum[h] += __shfl_xor(ssum[h], 32, 64);
-        qsum[h] += __shfl_xor(qsum[h], 16, 64); qsum[h] += __shfl_xor(qsum[h], 32, 64);
     }
     // C layout: lane (kq, m) holds rows 4*kq + r, column 16*nt + m
 #pragma unroll
@@ -164,16 +156,12 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int i = i0 + 4 * kq + r;
             const float s = __shfl(ssum[h], 4 * kq + r, 64);
-            const float qv = __shfl(qsum[h], 4 * kq + r, 64);
             const float mrow = __shfl(mx[h], 4 * kq + r, 64);
             const float inv = s > 0.f ? 1.0f / s : 0.f;
             if (i >= N) continue;
             const int64_t node = b * N + i;
             if constexpr (SAVE) {
-                if (m == 0) {
-                    a.lse[node * H + h] = mrow + logf(s);
-                    a.q[node * H + h] = qv * inv;
-                }
+                if (m == 0) a.lse[node * H + h] = mrow + logf(s);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -182,10 +170,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
                     const int64_t o = (node * H + h) * FP + c;
                     const float t2 = acc2[h][nt][r] * inv;
                     a.out[node * a.ld_out + h * FP + c] = m1v[h] * (m2v[h] * accU[nt][r] + accV[nt][r]) + t2;
-                    if constexpr (SAVE) {
-                        a.t2n[o] = t2;
-                        a.t2pos[o] = acc2p[h][nt][r] * inv;
-                    }
+                    if constexpr (SAVE) a.t2n[o] = t2;
                 }
             }
         }
@@ -194,11 +179,11 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
 
 struct BnfBwdArgs {
     int N;
-    const float *G, *stats, *X, *A, *f2, *m1, *m2;
-    float *dX, *dA, *df2, *ws;
+    const float *G, *stats, *X, *A, *f2, *m1, *m2;    // stats [nodes, H] x {f1, lse, c, -}
+    float *dX, *dA, *df1p, *df2, *ws;                  // df1p [source blocks][nodes, H]: every block's share of df1
     float slope;
     int accumulate;             // dX, dA: add to what is there (a later group of heads of the same step)
-    int64_t nodes, pairs;       // B * N, B * N * N: group g (blockIdx.z) reads G, stats, f2 and writes dX, dA, df2, ws at + g * its size
+    int64_t nodes, pairs;       // B * N, B * N * N: group g (blockIdx.z) reads G, stats, f2 and writes dX, dA, df1p, df2, ws at + g * its size
 };
 
 // Block (b, 64 sources): wave w owns sources 16*w .. 16*w+15, all heads, and walks all destinations.
@@ -212,6 +197,7 @@ __global__ __launch_bounds__(256) void bnf_attn_bwd_kernel(BnfBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float gs[kBnfJC * LDG];       // G rows (all heads) of the destination chunk
     __shared__ __attribute__((aligned(16))) float ss[kBnfJC * H * 4];     // {f1, lse, c, -}
     __shared__ float red[4][2 * H];
+    __shared__ float p1[4][kBnfJC * H];                                    // every wave's share of df1 for the chunk's rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;
     const int N = a.N;
@@ -221,7 +207,8 @@ __global__ __launch_bounds__(256) void bnf_attn_bwd_kernel(BnfBwdArgs a) {
     const bool jok = j0 + m < N;
     {
         const int64_t g = blockIdx.z;
-        a.G += g * a.nodes * W; a.stats += g * a.nodes * (3 * H); a.f2 += g * a.nodes * H;
+        a.G += g * a.nodes * W; a.stats += g * a.nodes * (4 * H); a.f2 += g * a.nodes * H;
+        a.df1p += g * (int64_t)gridDim.y * a.nodes * H;
         a.m1 += g * H; a.m2 += g * H;
         a.dX += g * a.nodes * FP; a.dA += g * a.pairs; a.df2 += g * a.nodes * H;
         a.ws += g * (int64_t)gridDim.x * gridDim.y * (2 * H);
@@ -252,16 +239,13 @@ __global__ __launch_bounds__(256) void bnf_attn_bwd_kernel(BnfBwdArgs a) {
             *reinterpret_cast<float2 *>(gs + r * LDG + 2 * c) = v;
         }
         for (int e = threadIdx.x; e < kBnfJC * H; e += 256) {
-            const int r = e / H, h = e % H;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ic + r < N) {
-                const float *st = a.stats + (b * N + ic + r) * (int64_t)(3 * H) + h;
-                v = make_float4(st[0], st[H], st[2 * H], 0.f);
-            }
+            if (ic + e / H < N) v = *reinterpret_cast<const float4 *>(a.stats + ((b * N + ic) * (int64_t)H + e) * 4);
             *reinterpret_cast<float4 *>(ss + e * 4) = v;
         }
+        for (int e = threadIdx.x; e < 4 * kBnfJC * H; e += 256) (&p1[0][0])[e] = 0.f;
         __syncthreads();
-        if (j0 >= N) continue;
+        if (j0 < N) {
         const int iend = min(kBnfJC, N - ic);
         for (int il = 0; il < iend; il += 16) {
             float av[4], th[4], dA[4];
@@ -294,7 +278,10 @@ __global__ __launch_bounds__(256) void bnf_attn_bwd_kernel(BnfBwdArgs a) {
                         dm1[h] += n * D[r];
                         dm2[h] += th[r] * dn;
                     }
-                    df2[h] += C * (n * D[r] - st.z) * (z > 0.f ? 1.f : a.slope);
+                    const float dl = C * (n * D[r] - st.z) * (z > 0.f ? 1.f : a.slope);      // 0 where !ok: C = 0
+                    df2[h] += dl;
+                    const float rowsum = group_sum<16>(dl);                                    // over the wave's 16 sources
+                    if (m == 0) p1[wave][(il + 4 * kq + r) * H + h] = rowsum;
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -315,6 +302,11 @@ __global__ __launch_bounds__(256) void bnf_attn_bwd_kernel(BnfBwdArgs a) {
                 }
             }
         }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < kBnfJC * H; e += 256)
+            if (ic + e / H < N)
+                a.df1p[((int64_t)blockIdx.y * a.nodes + b * N + ic) * H + e] = (p1[0][e] + p1[1][e]) + (p1[2][e] + p1[3][e]);
     }
     // per-wave totals of dm1 / dm2 -> block partial (fixed order) -> ws[block][2H]
 #pragma unroll
@@ -367,8 +359,24 @@ __global__ void bnf_dm_reduce_kernel(const float *ws, int nblocks, int width, fl
     if (ok && threadIdx.y == 0) out[c] = t;
 }
 
-// dst[e] (+)= sum over groups of part[g][e], in group order
+// stats[row] = {f1, lse, c = <G_row, t2n_row>, 0} for every (group, node, head) row of FP floats; 64 / LP rows per wave
+template <int FP>
+__global__ __launch_bounds__(256) void bnf_row_stats_kernel(const float *G, const float *t2n, const float *f1, const float *lse,
+                                                            int64_t rows, float *stats) {
+    constexpr int LP = FP / 4;                                    // lanes per row, a float4 each
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LP) + lane / LP;
+    const bool ok = row < rows;
+    const int64_t o = (ok ? row : 0) * FP + 4 * (lane % LP);
+    const float4 g = *reinterpret_cast<const float4 *>(G + o), t = *reinterpret_cast<const float4 *>(t2n + o);
+    const float c = group_sum<LP>((g.x * t.x + g.y * t.y) + (g.z * t.z + g.w * t.w));
+    if (ok && lane % LP == 0) *reinterpret_cast<float4 *>(stats + row * 4) = make_float4(f1[row], lse[row], c, 0.f);
+}
+
+// dst[e] (+)= sum over groups of part[g][e], in group order; blockIdx.y: one such sum per slab of part and dst
 __global__ __launch_bounds__(256) void bnf_group_sum_kernel(const float *part, int groups, int64_t count, int accumulate, float *dst) {
+    part += (int64_t)blockIdx.y * groups * count;
+    dst += (int64_t)blockIdx.y * count;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < count; e += stride) {
         float t = accumulate ? dst[e] : 0.f;
@@ -394,7 +402,7 @@ static int bnf_check(int64_t B, int32_t N, int32_t H, int32_t fp, const char *na
 extern "C" int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
                                   const float *X, const float *A, const float *f1, const float *f2,
                                   const float *m1, const float *m2, float slope,
-                                  float *out, int64_t ld_out, float *t2n, float *t2pos, float *lse, float *q, int32_t groups, void *stream) {
+                                  float *out, int64_t ld_out, float *t2n, float *lse, int32_t groups, void *stream) {
     int rc = bnf_check(B, N, H, fp, "bnf_attn_fwd");
     if (rc) return rc;
     GATMI_REQUIRE(groups >= 1 && groups <= 1024, GATMI_EINVAL, "bnf_attn_fwd: groups must be 1..1024");
@@ -402,12 +410,12 @@ extern "C" int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
     GATMI_REQUIRE(X && A && f1 && f2 && m1 && m2 && out, GATMI_EINVAL, "bnf_attn_fwd: null pointer");
     if (ld_out == 0) ld_out = (int64_t)groups * H * fp;
     GATMI_REQUIRE(ld_out >= (int64_t)groups * H * fp, GATMI_EINVAL, "bnf_attn_fwd: ld_out %lld is less than the %d floats of a row", (long long)ld_out, groups * H * fp);
-    const bool save = t2n || t2pos || lse || q;
-    GATMI_REQUIRE(!save || (t2n && t2pos && lse && q), GATMI_EINVAL, "bnf_attn_fwd: t2n, t2pos, lse, q must be given together");
+    const bool save = t2n || lse;
+    GATMI_REQUIRE(!save || (t2n && lse), GATMI_EINVAL, "bnf_attn_fwd: t2n and lse must be given together");
     GATMI_REQUIRE_ALIGNED(X); GATMI_REQUIRE_ALIGNED(A);
     BnfFwdArgs a;
     a.N = N; a.X = X; a.A = A; a.f1 = f1; a.f2 = f2; a.m1 = m1; a.m2 = m2;
-    a.out = out; a.t2n = t2n; a.t2pos = t2pos; a.lse = lse; a.q = q; a.slope = slope; a.ld_out = ld_out; a.nodes = B * N;
+    a.out = out; a.t2n = t2n; a.lse = lse; a.slope = slope; a.ld_out = ld_out; a.nodes = B * N;
     const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64), (unsigned)groups);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X_(ff, hh)                                                                                  \
@@ -422,43 +430,57 @@ extern "C" int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
     return fail(GATMI_EUNSUPPORTED, "bnf_attn_fwd: no kernel for fp=%d H=%d", fp, H);
 }
 
+static size_t bnf_bwd_blocks(int64_t B, int32_t N) { return (size_t)B * (size_t)((N + 63) / 64); }
+
 extern "C" size_t gatmi_bnf_attn_bwd_ws_floats(int64_t B, int32_t N, int32_t H, int32_t fp, int32_t groups) {
-    const size_t dm = (size_t)B * (size_t)((N + 63) / 64) * (size_t)(2 * H) * (size_t)groups;
+    const size_t nodes = (size_t)B * N, jb = (size_t)((N + 63) / 64);
+    const size_t stats = (size_t)groups * nodes * H * 4;
+    const size_t df1p = (size_t)groups * jb * nodes * H;
+    const size_t dm = bnf_bwd_blocks(B, N) * (size_t)(2 * H) * (size_t)groups;
     // several groups in one launch: every group's share of dX and dA, summed afterwards
-    return dm + (groups > 1 ? (size_t)groups * ((size_t)B * N * fp + (size_t)B * N * N) : 0);
+    return stats + df1p + dm + (groups > 1 ? (size_t)groups * (nodes * fp + nodes * N) : 0);
 }
 
 extern "C" int gatmi_bnf_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t fp,
-                                  const float *G, const float *stats, const float *X, const float *A,
+                                  const float *G, const float *t2n, const float *f1, const float *lse,
+                                  const float *X, const float *A,
                                   const float *f2, const float *m1, const float *m2, float slope,
-                                  float *dX, float *dA, int accumulate, float *df2, float *dm, float *ws, int32_t groups, void *stream) {
+                                  float *dX, float *dA, int accumulate, float *df1, float *df2, float *dm, float *ws, int32_t groups, void *stream) {
     int rc = bnf_check(B, N, H, fp, "bnf_attn_bwd");
     if (rc) return rc;
     GATMI_REQUIRE(groups >= 1 && groups <= 1024, GATMI_EINVAL, "bnf_attn_bwd: groups must be 1..1024");
     if (B == 0 || N == 0) return GATMI_OK;
-    GATMI_REQUIRE(G && stats && X && A && f2 && m1 && m2 && dX && dA && df2 && dm && ws, GATMI_EINVAL, "bnf_attn_bwd: null pointer");
-    GATMI_REQUIRE_ALIGNED(G);
+    GATMI_REQUIRE(G && t2n && f1 && lse && X && A && f2 && m1 && m2 && dX && dA && df1 && df2 && dm && ws, GATMI_EINVAL, "bnf_attn_bwd: null pointer");
+    GATMI_REQUIRE_ALIGNED(G); GATMI_REQUIRE_ALIGNED(t2n); GATMI_REQUIRE_ALIGNED(ws);
+    const int64_t nodes = B * N, pairs = nodes * N;
+    const int jb = (N + 63) / 64;
+    const int nblocks = (int)bnf_bwd_blocks(B, N);
+    float *stats = ws;
+    float *df1p = stats + (size_t)groups * nodes * H * 4;
+    float *dmws = df1p + (size_t)groups * jb * nodes * H;
+    float *part = dmws + (size_t)nblocks * (2 * H) * groups;               // [groups][dX] then [groups][dA]
     BnfBwdArgs a;
     a.N = N; a.G = G; a.stats = stats; a.X = X; a.A = A; a.f2 = f2; a.m1 = m1; a.m2 = m2;
-    a.dX = dX; a.dA = dA; a.df2 = df2; a.ws = ws; a.slope = slope; a.accumulate = accumulate;
-    a.nodes = B * N; a.pairs = B * N * (int64_t)N;
-    const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64), (unsigned)groups);
-    const int nblocks = (int)(grid.x * grid.y);
-    float *part = ws + (size_t)nblocks * (2 * H) * groups;        // [groups][dX | ...] then [groups][dA]
-    if (groups > 1) {
-        GATMI_REQUIRE_ALIGNED(ws);
-        a.dX = part; a.dA = part + (size_t)groups * a.nodes * fp; a.accumulate = 0;
-    }
+    a.dX = dX; a.dA = dA; a.df1p = df1p; a.df2 = df2; a.ws = dmws; a.slope = slope; a.accumulate = accumulate;
+    a.nodes = nodes; a.pairs = pairs;
+    if (groups > 1) { a.dX = part; a.dA = part + (size_t)groups * nodes * fp; a.accumulate = 0; }
+    const dim3 grid((unsigned)B, (unsigned)jb, (unsigned)groups);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t rows = (int64_t)groups * nodes * H;
 #define X_(ff, hh)                                                                         \
     if (fp == ff && H == hh) {                                                             \
+        const int64_t per_block = 4 * (64 / (ff / 4));                                     \
+        hipLaunchKernelGGL(bnf_row_stats_kernel<ff>, dim3((unsigned)((rows + per_block - 1) / per_block)), dim3(256), 0, st, G, t2n, f1, lse, rows, stats); \
+        GATMI_LAUNCH_CHECK("bnf_row_stats");                                               \
         hipLaunchKernelGGL((bnf_attn_bwd_kernel<ff, hh>), grid, dim3(256), 0, st, a);       \
         GATMI_LAUNCH_CHECK("bnf_attn_bwd");                                                \
-        hipLaunchKernelGGL(bnf_dm_reduce_kernel, dim3(1, groups), dim3(kSumCols, kSumRows), 0, st, ws, nblocks, 2 * hh, dm); \
+        hipLaunchKernelGGL(bnf_dm_reduce_kernel, dim3(1, groups), dim3(kSumCols, kSumRows), 0, st, dmws, nblocks, 2 * hh, dm); \
         GATMI_LAUNCH_CHECK("bnf_dm_reduce");                                               \
+        hipLaunchKernelGGL(bnf_group_sum_kernel, dim3((unsigned)std::min<int64_t>(1024, (nodes * hh + 255) / 256), groups), dim3(256), 0, st, df1p, jb, nodes * hh, 0, df1); \
+        GATMI_LAUNCH_CHECK("bnf_df1_sum");                                                 \
         if (groups > 1) {                                                                  \
-            hipLaunchKernelGGL(bnf_group_sum_kernel, dim3((unsigned)std::min<int64_t>(2048, (a.nodes * fp + 255) / 256)), dim3(256), 0, st, a.dX, groups, a.nodes * fp, accumulate, dX); \
-            hipLaunchKernelGGL(bnf_group_sum_kernel, dim3((unsigned)std::min<int64_t>(2048, (a.pairs + 255) / 256)), dim3(256), 0, st, a.dA, groups, a.pairs, accumulate, dA); \
+            hipLaunchKernelGGL(bnf_group_sum_kernel, dim3((unsigned)std::min<int64_t>(2048, (nodes * fp + 255) / 256)), dim3(256), 0, st, a.dX, groups, nodes * fp, accumulate, dX); \
+            hipLaunchKernelGGL(bnf_group_sum_kernel, dim3((unsigned)std::min<int64_t>(2048, (pairs + 255) / 256)), dim3(256), 0, st, a.dA, groups, pairs, accumulate, dA); \
             GATMI_LAUNCH_CHECK("bnf_group_sum");                                           \
         }                                                                                  \
         return GATMI_OK;                                                                   \
