@@ -27,18 +27,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBnfJC = 64;      // sources (forward) / destinations (backward) staged in LDS per step
 constexpr int kBnfBlocksMax = 1 << 20;
+constexpr int kBnfUVBlocks = 512;   // blocks per group from which the head-independent sums get a pass of their own (below: a launch more costs more than it saves)
 
 struct BnfFwdArgs {
     int N;
     const float *X, *A, *f1, *f2, *m1, *m2;
     float *out, *t2n, *lse;
+    float *uv;                  // [2][nodes][FP]: U = [A>0].X and V = A.X, written by the UV pass and read by the heads pass
     float slope;
     int64_t ld_out;             // floats between rows of out (>= groups * H * FP): a call may fill its heads' share of wider rows
     int64_t nodes;              // B * N: group g (blockIdx.z) reads f1, f2 at + g * nodes * H, saves at + g * nodes * H (* FP)
 };
 
 // Block (b, 64 destination rows): wave w owns rows 16*w .. 16*w+15 and all H heads.
-template <int FP, int H, bool SAVE>
+// MODE kBnfAll: everything in one pass.  U and V do not depend on the head, so a launch that covers several groups of
+// heads would form them once per group: kBnfUV forms them alone (no softmax work) and kBnfHeads reads them back.
+constexpr int kBnfAll = 0, kBnfUV = 1, kBnfHeads = 2;
+template <int FP, int H, bool SAVE, int MODE = kBnfAll>
 __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
     constexpr int LD = FP + 4;
     constexpr int NT = (FP + 15) / 16;
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
         m2v[h] = a.m2[h];
     }
     // ---- sweep 1: row maxima of LeakyReLU(f1_i + f2_j) --------------------------------------
-    for (int jc = 0; jc < N; jc += kBnfJC) {
+    for (int jc = 0; MODE != kBnfUV && jc < N; jc += kBnfJC) {
         __syncthreads();
         for (int e = threadIdx.x; e < kBnfJC * H; e += 256) f2s[e] = (jc + e / H < N) ? f2b[(int64_t)jc * H + e] : -INFINITY;
         __syncthreads();
@@ -107,7 +112,8 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
             if (jc + r < N) v = *reinterpret_cast<const float4 *>(a.X + (b * N + jc + r) * (int64_t)FP + 4 * c);
             *reinterpret_cast<float4 *>(xs + r * LD + 4 * c) = v;
         }
-        for (int e = threadIdx.x; e < kBnfJC * H; e += 256) f2s[e] = (jc + e / H < N) ? f2b[(int64_t)jc * H + e] : -INFINITY;
+        if constexpr (MODE != kBnfUV)
+            for (int e = threadIdx.x; e < kBnfJC * H; e += 256) f2s[e] = (jc + e / H < N) ? f2b[(int64_t)jc * H + e] : -INFINITY;
         __syncthreads();
         const int jend = min(kBnfJC, N - jc);
         for (int jl = 0; jl < jend; jl += 16) {
@@ -127,13 +133,15 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) xr[nt] = NARROW ? xrow[mcl] * maskf : xrow[16 * nt + m];
                 const float th = av[t] > 0.f ? 1.f : 0.f;
+                if constexpr (MODE != kBnfHeads) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    accU[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(th, xr[nt], accU[nt], 0, 0, 0);
-                    accV[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], xr[nt], accV[nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        accU[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(th, xr[nt], accU[nt], 0, 0, 0);
+                        accV[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], xr[nt], accV[nt], 0, 0, 0);
+                    }
                 }
 #pragma unroll
-                for (int h = 0; h < H; ++h) {
+                for (int h = 0; MODE != kBnfUV && h < H; ++h) {
                     const float z = f1v[h] + f2s[(jl + 4 * kq + t) * H + h];     // -inf for j >= N => p = 0
                     const float p = exp_neg(leaky(z, a.slope) - mx[h]);
                     ssum[h] += p;
@@ -145,6 +153,22 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
         }
     }
     if (i0 >= N) return;
+    if constexpr (MODE == kBnfUV) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 4 * kq + r;
+            if (i >= N) continue;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = 16 * nt + m;
+                if (c < FP) {
+                    a.uv[(b * N + i) * FP + c] = accU[nt][r];
+                    a.uv[(a.nodes + b * N + i) * FP + c] = accV[nt][r];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         ssum[h] += __shfl_xor(ssum[h], 16, 64); ssum[h] += __shfl_xor(ssum[h], 32, 64);
@@ -169,7 +193,9 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
                 if (c < FP) {
                     const int64_t o = (node * H + h) * FP + c;
                     const float t2 = acc2[h][nt][r] * inv;
-                    a.out[node * a.ld_out + h * FP + c] = m1v[h] * (m2v[h] * accU[nt][r] + accV[nt][r]) + t2;
+                    const float u = MODE == kBnfHeads ? a.uv[node * FP + c] : accU[nt][r];
+                    const float v = MODE == kBnfHeads ? a.uv[(a.nodes + node) * FP + c] : accV[nt][r];
+                    a.out[node * a.ld_out + h * FP + c] = m1v[h] * (m2v[h] * u + v) + t2;
                     if constexpr (SAVE) a.t2n[o] = t2;
                 }
             }
@@ -399,15 +425,19 @@ static int bnf_check(int64_t B, int32_t N, int32_t H, int32_t fp, const char *na
     return GATMI_OK;
 }
 
+extern "C" size_t gatmi_bnf_attn_fwd_ws_floats(int64_t B, int32_t N, int32_t fp, int32_t groups) {
+    return groups > 1 ? 2 * (size_t)B * N * fp : 1;
+}
+
 extern "C" int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
                                   const float *X, const float *A, const float *f1, const float *f2,
                                   const float *m1, const float *m2, float slope,
-                                  float *out, int64_t ld_out, float *t2n, float *lse, int32_t groups, void *stream) {
+                                  float *out, int64_t ld_out, float *t2n, float *lse, float *ws, int32_t groups, void *stream) {
     int rc = bnf_check(B, N, H, fp, "bnf_attn_fwd");
     if (rc) return rc;
     GATMI_REQUIRE(groups >= 1 && groups <= 1024, GATMI_EINVAL, "bnf_attn_fwd: groups must be 1..1024");
     if (B == 0 || N == 0) return GATMI_OK;
-    GATMI_REQUIRE(X && A && f1 && f2 && m1 && m2 && out, GATMI_EINVAL, "bnf_attn_fwd: null pointer");
+    GATMI_REQUIRE(X && A && f1 && f2 && m1 && m2 && out && (groups == 1 || ws), GATMI_EINVAL, "bnf_attn_fwd: null pointer");
     if (ld_out == 0) ld_out = (int64_t)groups * H * fp;
     GATMI_REQUIRE(ld_out >= (int64_t)groups * H * fp, GATMI_EINVAL, "bnf_attn_fwd: ld_out %lld is less than the %d floats of a row", (long long)ld_out, groups * H * fp);
     const bool save = t2n || lse;
@@ -415,12 +445,16 @@ extern "C" int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
     GATMI_REQUIRE_ALIGNED(X); GATMI_REQUIRE_ALIGNED(A);
     BnfFwdArgs a;
     a.N = N; a.X = X; a.A = A; a.f1 = f1; a.f2 = f2; a.m1 = m1; a.m2 = m2;
-    a.out = out; a.t2n = t2n; a.lse = lse; a.slope = slope; a.ld_out = ld_out; a.nodes = B * N;
+    a.out = out; a.t2n = t2n; a.lse = lse; a.uv = ws; a.slope = slope; a.ld_out = ld_out; a.nodes = B * N;
     const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64), (unsigned)groups);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X_(ff, hh)                                                                                  \
     if (fp == ff && H == hh) {                                                                      \
-        if (save) hipLaunchKernelGGL((bnf_attn_fwd_kernel<ff, hh, true>), grid, dim3(256), 0, st, a); \
+        if (groups > 1 && (int64_t)grid.x * grid.y >= kBnfUVBlocks) {                               \
+            hipLaunchKernelGGL((bnf_attn_fwd_kernel<ff, hh, false, kBnfUV>), dim3(grid.x, grid.y), dim3(256), 0, st, a); \
+            if (save) hipLaunchKernelGGL((bnf_attn_fwd_kernel<ff, hh, true, kBnfHeads>), grid, dim3(256), 0, st, a); \
+            else hipLaunchKernelGGL((bnf_attn_fwd_kernel<ff, hh, false, kBnfHeads>), grid, dim3(256), 0, st, a);   \
+        } else if (save) hipLaunchKernelGGL((bnf_attn_fwd_kernel<ff, hh, true>), grid, dim3(256), 0, st, a); \
         else hipLaunchKernelGGL((bnf_attn_fwd_kernel<ff, hh, false>), grid, dim3(256), 0, st, a);     \
         GATMI_LAUNCH_CHECK("bnf_attn_fwd");                                                         \
         return GATMI_OK;                                                                            \

@@ -642,8 +642,9 @@ class BnfAggregateFn(torch.autograd.Function):
             t2n = lse = None
             if need_grad:
                 t2n, lse = _new((groups, n, hg * fp), x), _new((groups, n, hg), x)
+            wsf = _new((_lib.lib.gatmi_bnf_attn_fwd_ws_floats(B, N, fp, groups),), x) if groups > 1 else None
             _lib.call("gatmi_bnf_attn_fwd", B, N, hg, fp, ptr(xp), ptr(A), ptr(f[0]), ptr(f[1]), ptr(m1c[h0:]), ptr(m2c[h0:]), slope,
-                      ptr(out[:, h0 * fp:]), H * fp, ptr(t2n), ptr(lse), groups, st)
+                      ptr(out[:, h0 * fp:]), H * fp, ptr(t2n), ptr(lse), ptr(wsf), groups, st)
             saved += [f, t2n, lse]
         if need_grad:
             ctx.dims, ctx.slope = (B, N, F, H, fp), slope

@@ -503,11 +503,14 @@ int gatmi_scale_by_device_scalar(float *x, int64_t n, const float *scale, void *
  *   groups > 1: one launch for groups x H heads of the same step (the reference runs n_heads of these steps on one
  *   input, :173; at its batch of 50 a launch for two heads fills a fraction of the chip): f1, f2, lse are
  *   [groups,B,N,H], t2n [groups,B,N,H,fp], m1, m2 [groups*H], and row (b,i) of out holds the groups one after
- *   the other (ld_out >= groups*H*fp). */
+ *   the other (ld_out >= groups*H*fp); the two sums that do not depend on the head ([A>0].X and A.X) are then formed
+ *   once, by a pass of their own, through ws: gatmi_bnf_attn_fwd_ws_floats(B, N, fp, groups) floats (NULL for
+ *   groups = 1). */
+size_t gatmi_bnf_attn_fwd_ws_floats(int64_t B, int32_t N, int32_t fp, int32_t groups);
 int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
                        const float *X, const float *A, const float *f1, const float *f2,
                        const float *m1, const float *m2, float slope,
-                       float *out, int64_t ld_out, float *t2n, float *lse, int32_t groups, void *stream);
+                       float *out, int64_t ld_out, float *t2n, float *lse, float *ws, int32_t groups, void *stream);
 
 /* Backward of the above.  G [B,N,H,fp] = gradient of out (contiguous); t2n, f1, lse, f2 as the forward call had them.
  * Outputs: dX [B,N,fp] (aggregation part only), dA [B,N,N], df1, df2 [B,N,H] (gradients of the logit halves:
