@@ -216,7 +216,7 @@ struct BnfBwdArgs {
 template <int FP, int H>
 __global__ __launch_bounds__(256) void bnf_attn_bwd_kernel(BnfBwdArgs a) {
     constexpr int W = H * FP;
-    constexpr int LDG = W + 2;
+    constexpr int LDG = W + 4;                 // rows 4 banks apart: the A reads (row m, column kq) and the B reads (row 4 kq + r, column m) of a wave hit 64 banks
     constexpr int NT = (FP + 15) / 16;
     constexpr int KS = FP / 4;
     constexpr bool NARROW = FP < 16;
