@@ -32,7 +32,7 @@ constexpr int kBnfUVBlocks = 512;   // blocks per group from which the head-inde
 struct BnfFwdArgs {
     int N;
     const float *X, *A, *f1, *f2, *m1, *m2;
-    float *out, *t2n, *lse;
+    float *out, *t2n, *lse, *q;
     float *uv;                  // [2][nodes][FP]: U = [A>0].X and V = A.X, written by the UV pass and read by the heads pass
     float slope;
     int64_t ld_out;             // floats between rows of out (>= groups * H * FP): a call may fill its heads' share of wider rows
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
     a.f1 += goff; a.f2 += goff;
     a.m1 += blockIdx.z * H; a.m2 += blockIdx.z * H;
     a.out += blockIdx.z * (H * FP);
-    if constexpr (SAVE) { a.t2n += goff * FP; a.lse += goff; }
+    if constexpr (SAVE) { a.t2n += goff * FP; a.lse += goff; a.q += goff; }
     const float *f2b = a.f2 + b * N * (int64_t)H;
     const bool vec = (N & 3) == 0;
     const float maskf = (!NARROW || m < FP) ? 1.f : 0.f;
@@ -95,12 +95,12 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
     }
     // ---- sweep 2 ----------------------------------------------------------------------------------
     f32x4 accU[NT], accV[NT], acc2[H][NT];
-    float ssum[H];
+    float ssum[H], qsum[H];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) accU[nt] = accV[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-        ssum[h] = 0.f;
+        ssum[h] = qsum[h] = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc2[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
                     const float z = f1v[h] + f2s[(jl + 4 * kq + t) * H + h];     // -inf for j >= N => p = 0
                     const float p = exp_neg(leaky(z, a.slope) - mx[h]);
                     ssum[h] += p;
+                    if constexpr (SAVE) qsum[h] += z > 0.f ? p : 0.f;
                     const float np_ = (m2v[h] * th + av[t]) * p;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc2[h][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(np_, xr[nt], acc2[h][nt], 0, 0, 0);
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         ssum[h] += __shfl_xor(ssum[h], 16, 64); ssum[h] += __shfl_xor(ssum[h], 32, 64);
+        if constexpr (SAVE) { qsum[h] += __shfl_xor(qsum[h], 16, 64); qsum[h] += __shfl_xor(qsum[h], 32, 64); }
     }
     // C layout: lane (kq, m) holds rows 4*kq + r, column 16*nt + m
 #pragma unroll
@@ -181,11 +183,15 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
             const int i = i0 + 4 * kq + r;
             const float s = __shfl(ssum[h], 4 * kq + r, 64);
             const float mrow = __shfl(mx[h], 4 * kq + r, 64);
+            const float qv = SAVE ? __shfl(qsum[h], 4 * kq + r, 64) : 0.f;
             const float inv = s > 0.f ? 1.0f / s : 0.f;
             if (i >= N) continue;
             const int64_t node = b * N + i;
             if constexpr (SAVE) {
-                if (m == 0) a.lse[node * H + h] = mrow + logf(s);
+                if (m == 0) {
+                    a.lse[node * H + h] = mrow + logf(s);
+                    a.q[node * H + h] = qv * inv;      // share of the row's softmax mass that lies on positive logits
+                }
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
 
 struct BnfBwdArgs {
     int N;
-    const float *G, *stats, *X, *A, *f2, *m1, *m2;    // stats [nodes, H] x {f1, lse, c, -}
+    const float *G, *stats, *X, *A, *f2, *m1, *m2;    // stats [nodes, H] x {f1, lse, c, mean slope}
     float *dX, *dA, *df1p, *df2, *ws;                  // df1p [source blocks][nodes, H]: every block's share of df1
     float slope;
     int accumulate;             // dX, dA: add to what is there (a later group of heads of the same step)
@@ -214,7 +220,7 @@ struct BnfBwdArgs {
 
 // Block (b, 64 sources): wave w owns sources 16*w .. 16*w+15, all heads, and walks all destinations.
 template <int FP, int H>
-__global__ __launch_bounds__(256) void bnf_attn_bwd_kernel(BnfBwdArgs a) {
+__global__ __launch_bounds__(256, 3) void bnf_attn_bwd_kernel(BnfBwdArgs a) {      // three waves per SIMD: at most 168 registers
     constexpr int W = H * FP;
     constexpr int LDG = W + 4;                 // rows 4 banks apart: the A reads (row m, column kq) and the B reads (row 4 kq + r, column m) of a wave hit 64 banks
     constexpr int NT = (FP + 15) / 16;
@@ -304,9 +310,13 @@ __global__ __launch_bounds__(256) void bnf_attn_bwd_kernel(BnfBwdArgs a) {
                         dm1[h] += n * D[r];
                         dm2[h] += th[r] * dn;
                     }
-                    const float dl = C * (n * D[r] - st.z) * (z > 0.f ? 1.f : a.slope);      // 0 where !ok: C = 0
-                    df2[h] += dl;
-                    const float rowsum = group_sum<16>(dl);                                    // over the wave's 16 sources
+                    const float cnd = C * n * D[r];                                            // 0 where !ok: C = 0
+                    const float sp = z > 0.f ? 1.f : a.slope;
+                    df2[h] += (cnd - C * st.z) * sp;
+                    // df1_i = sum_j C (n D - c_i) sp with c_i = sum_j C n D  =  sum_j C n D (sp_ij - mean slope of row i): each
+                    // term is exactly 0 in a row whose logits all lie on one side of the kink, and no c_i from another
+                    // summation order enters.  Summed over the wave's 16 sources here.
+                    const float rowsum = group_sum<16>(cnd * (sp - st.w));
                     if (m == 0) p1[wave][(il + 4 * kq + r) * H + h] = rowsum;
                 }
 #pragma unroll
@@ -385,10 +395,11 @@ __global__ void bnf_dm_reduce_kernel(const float *ws, int nblocks, int width, fl
     if (ok && threadIdx.y == 0) out[c] = t;
 }
 
-// stats[row] = {f1, lse, c = <G_row, t2n_row>, 0} for every (group, node, head) row of FP floats; 64 / LP rows per wave
+// stats[row] = {f1, lse, c = <G_row, t2n_row>, mean slope = slope + (1 - slope) q} for every (group, node, head) row of
+// FP floats (q: the share of the row's softmax mass on positive logits); 64 / LP rows per wave
 template <int FP>
 __global__ __launch_bounds__(256) void bnf_row_stats_kernel(const float *G, const float *t2n, const float *f1, const float *lse,
-                                                            int64_t rows, float *stats) {
+                                                            const float *q, float slope, int64_t rows, float *stats) {
     constexpr int LP = FP / 4;                                    // lanes per row, a float4 each
     const int lane = threadIdx.x & 63;
     const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LP) + lane / LP;
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(256) void bnf_row_stats_kernel(const float *G, cons
     const int64_t o = (ok ? row : 0) * FP + 4 * (lane % LP);
     const float4 g = *reinterpret_cast<const float4 *>(G + o), t = *reinterpret_cast<const float4 *>(t2n + o);
     const float c = group_sum<LP>((g.x * t.x + g.y * t.y) + (g.z * t.z + g.w * t.w));
-    if (ok && lane % LP == 0) *reinterpret_cast<float4 *>(stats + row * 4) = make_float4(f1[row], lse[row], c, 0.f);
+    if (ok && lane % LP == 0) *reinterpret_cast<float4 *>(stats + row * 4) = make_float4(f1[row], lse[row], c, slope + (1.f - slope) * q[row]);
 }
 
 // dst[e] (+)= sum over groups of part[g][e], in group order; blockIdx.y: one such sum per slab of part and dst
@@ -432,7 +443,7 @@ extern "C" size_t gatmi_bnf_attn_fwd_ws_floats(int64_t B, int32_t N, int32_t fp,
 extern "C" int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
                                   const float *X, const float *A, const float *f1, const float *f2,
                                   const float *m1, const float *m2, float slope,
-                                  float *out, int64_t ld_out, float *t2n, float *lse, float *ws, int32_t groups, void *stream) {
+                                  float *out, int64_t ld_out, float *t2n, float *lse, float *q, float *ws, int32_t groups, void *stream) {
     int rc = bnf_check(B, N, H, fp, "bnf_attn_fwd");
     if (rc) return rc;
     GATMI_REQUIRE(groups >= 1 && groups <= 1024, GATMI_EINVAL, "bnf_attn_fwd: groups must be 1..1024");
@@ -440,12 +451,12 @@ extern "C" int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
     GATMI_REQUIRE(X && A && f1 && f2 && m1 && m2 && out && (groups == 1 || ws), GATMI_EINVAL, "bnf_attn_fwd: null pointer");
     if (ld_out == 0) ld_out = (int64_t)groups * H * fp;
     GATMI_REQUIRE(ld_out >= (int64_t)groups * H * fp, GATMI_EINVAL, "bnf_attn_fwd: ld_out %lld is less than the %d floats of a row", (long long)ld_out, groups * H * fp);
-    const bool save = t2n || lse;
-    GATMI_REQUIRE(!save || (t2n && lse), GATMI_EINVAL, "bnf_attn_fwd: t2n and lse must be given together");
+    const bool save = t2n || lse || q;
+    GATMI_REQUIRE(!save || (t2n && lse && q), GATMI_EINVAL, "bnf_attn_fwd: t2n, lse and q must be given together");
     GATMI_REQUIRE_ALIGNED(X); GATMI_REQUIRE_ALIGNED(A);
     BnfFwdArgs a;
     a.N = N; a.X = X; a.A = A; a.f1 = f1; a.f2 = f2; a.m1 = m1; a.m2 = m2;
-    a.out = out; a.t2n = t2n; a.lse = lse; a.uv = ws; a.slope = slope; a.ld_out = ld_out; a.nodes = B * N;
+    a.out = out; a.t2n = t2n; a.lse = lse; a.q = q; a.uv = ws; a.slope = slope; a.ld_out = ld_out; a.nodes = B * N;
     const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64), (unsigned)groups);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X_(ff, hh)                                                                                  \
@@ -476,7 +487,7 @@ extern "C" size_t gatmi_bnf_attn_bwd_ws_floats(int64_t B, int32_t N, int32_t H, 
 }
 
 extern "C" int gatmi_bnf_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t fp,
-                                  const float *G, const float *t2n, const float *f1, const float *lse,
+                                  const float *G, const float *t2n, const float *f1, const float *lse, const float *q,
                                   const float *X, const float *A,
                                   const float *f2, const float *m1, const float *m2, float slope,
                                   float *dX, float *dA, int accumulate, float *df1, float *df2, float *dm, float *ws, int32_t groups, void *stream) {
@@ -484,7 +495,7 @@ extern "C" int gatmi_bnf_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t fp,
     if (rc) return rc;
     GATMI_REQUIRE(groups >= 1 && groups <= 1024, GATMI_EINVAL, "bnf_attn_bwd: groups must be 1..1024");
     if (B == 0 || N == 0) return GATMI_OK;
-    GATMI_REQUIRE(G && t2n && f1 && lse && X && A && f2 && m1 && m2 && dX && dA && df1 && df2 && dm && ws, GATMI_EINVAL, "bnf_attn_bwd: null pointer");
+    GATMI_REQUIRE(G && t2n && f1 && lse && q && X && A && f2 && m1 && m2 && dX && dA && df1 && df2 && dm && ws, GATMI_EINVAL, "bnf_attn_bwd: null pointer");
     GATMI_REQUIRE_ALIGNED(G); GATMI_REQUIRE_ALIGNED(t2n); GATMI_REQUIRE_ALIGNED(ws);
     const int64_t nodes = B * N, pairs = nodes * N;
     const int jb = (N + 63) / 64;
@@ -504,7 +515,7 @@ extern "C" int gatmi_bnf_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t fp,
 #define X_(ff, hh)                                                                         \
     if (fp == ff && H == hh) {                                                             \
         const int64_t per_block = 4 * (64 / (ff / 4));                                     \
-        hipLaunchKernelGGL(bnf_row_stats_kernel<ff>, dim3((unsigned)((rows + per_block - 1) / per_block)), dim3(256), 0, st, G, t2n, f1, lse, rows, stats); \
+        hipLaunchKernelGGL(bnf_row_stats_kernel<ff>, dim3((unsigned)((rows + per_block - 1) / per_block)), dim3(256), 0, st, G, t2n, f1, lse, q, slope, rows, stats); \
         GATMI_LAUNCH_CHECK("bnf_row_stats");                                               \
         hipLaunchKernelGGL((bnf_attn_bwd_kernel<ff, hh>), grid, dim3(256), 0, st, a);       \
         GATMI_LAUNCH_CHECK("bnf_attn_bwd");                                                \

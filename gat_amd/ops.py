@@ -639,13 +639,13 @@ class BnfAggregateFn(torch.autograd.Function):
         for h0, hg, groups in _bnf_head_sets(H):
             # [2, groups, n, hg]: every group's f1 rows, then every group's f2 rows
             f = f12[:, :, h0:h0 + groups * hg].reshape(n, 2, groups, hg).permute(1, 2, 0, 3).contiguous()
-            t2n = lse = None
+            t2n = lse = q = None
             if need_grad:
-                t2n, lse = _new((groups, n, hg * fp), x), _new((groups, n, hg), x)
+                t2n, lse, q = _new((groups, n, hg * fp), x), _new((groups, n, hg), x), _new((groups, n, hg), x)
             wsf = _new((_lib.lib.gatmi_bnf_attn_fwd_ws_floats(B, N, fp, groups),), x) if groups > 1 else None
             _lib.call("gatmi_bnf_attn_fwd", B, N, hg, fp, ptr(xp), ptr(A), ptr(f[0]), ptr(f[1]), ptr(m1c[h0:]), ptr(m2c[h0:]), slope,
-                      ptr(out[:, h0 * fp:]), H * fp, ptr(t2n), ptr(lse), ptr(wsf), groups, st)
-            saved += [f, t2n, lse]
+                      ptr(out[:, h0 * fp:]), H * fp, ptr(t2n), ptr(lse), ptr(q), ptr(wsf), groups, st)
+            saved += [f, t2n, lse, q]
         if need_grad:
             ctx.dims, ctx.slope = (B, N, F, H, fp), slope
             ctx.save_for_backward(xp, A, m1c, m2c, W, a12, Wc, *saved)
@@ -664,14 +664,14 @@ class BnfAggregateFn(torch.autograd.Function):
         df12 = _new((n, 2, H), xp)
         dm = _new((2, H), xp)
         for si, (h0, hg, groups) in enumerate(_bnf_head_sets(H)):
-            f, t2n, lse = per_set[3 * si:3 * si + 3]
+            f, t2n, lse, q = per_set[4 * si:4 * si + 4]
             heads = groups * hg
             # every group's rows of the incoming gradient contiguous: [groups, n, hg * fp]
             G = G_all[:, h0:h0 + heads].reshape(n, groups, hg * fp).transpose(0, 1).contiguous()
             df = _new((2, groups, n, hg), xp)                                 # df1 of every group, then df2
             dmg = _new((groups, 2, hg), xp)
             ws2 = _new((max(1, _lib.lib.gatmi_bnf_attn_bwd_ws_floats(B, N, hg, fp, groups)),), xp)
-            _lib.call("gatmi_bnf_attn_bwd", B, N, hg, fp, ptr(G), ptr(t2n), ptr(f[0]), ptr(lse), ptr(xp), ptr(A), ptr(f[1]), ptr(m1c[h0:]), ptr(m2c[h0:]), slope,
+            _lib.call("gatmi_bnf_attn_bwd", B, N, hg, fp, ptr(G), ptr(t2n), ptr(f[0]), ptr(lse), ptr(q), ptr(xp), ptr(A), ptr(f[1]), ptr(m1c[h0:]), ptr(m2c[h0:]), slope,
                       ptr(dx), ptr(dA), int(si > 0), ptr(df[0]), ptr(df[1]), ptr(dmg), ptr(ws2), groups, st)
             dm[:, h0:h0 + heads] = dmg.transpose(0, 1).reshape(2, heads)
             df12[:, :, h0:h0 + heads] = df.permute(2, 0, 1, 3).reshape(n, 2, heads)
