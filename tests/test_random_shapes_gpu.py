@@ -286,9 +286,9 @@ def test_decoder_and_bnf_random_draw(seed):
     _close(xt.grad.cpu().numpy(), rx.grad.numpy(), what + " dX", atol_scale=5e-6)
     _close(At.grad.cpu().numpy(), rA.grad.numpy(), what + " dA", atol_scale=5e-6)
     # The gradient of a logit half, df1_i = sum_j dlogit_ij, is a sum of terms of the size of |G||out| (tens, with 64
-    # features) that cancel to something often a hundred times smaller (exactly zero where a row's logits all lie on
-    # one side of LeakyReLU's kink): its fp32 error is absolute, ~1e-7 of those terms per node, and dW / da1 inherit
-    # it.  Band: 1e-4 relative + 3e-5 absolute for inputs of unit scale.
+    # features) that cancel to something often a hundred times smaller (zero where a row's logits all lie on one side
+    # of LeakyReLU's kink, which the kernel's form of the sum reproduces term by term): its fp32 error is absolute,
+    # ~1e-7 of those terms per node, and dW / da1 inherit it.  Band: 1e-4 relative + 3e-5 absolute for unit-scale inputs.
     for k in ("W", "a1", "a2", "m1", "m2"):
         got, want = getattr(mod, k).grad.cpu().numpy().astype(np.float64), rp[k].grad.numpy()
         tol = 1e-4 * np.abs(want) + 1e-4 * np.abs(want).max() + 3e-5
