@@ -1039,7 +1039,7 @@ static bool xt_lines_ok(const float *X, int64_t ldx, int f_in, const float *dY, 
 
 extern "C" size_t gatmi_linear_bwd_ws_floats(int64_t n, int32_t f_in, int32_t w) {
     if (n <= 0 || f_in <= 0 || w <= 0) return 1;
-    const size_t gx = (size_t)std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 63) / 64));
+    const size_t gx = (size_t)std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 4 * kNodeChunk - 1) / (4 * kNodeChunk)));
     const size_t fs = f_in <= 64 ? 64 : 128;
     const size_t lines = gx * (((size_t)f_in + fs - 1) / fs * fs) * (((size_t)w + 63) / 64 * 64);
     const int mt = dw_mt(f_in);
