@@ -92,7 +92,7 @@ def main():
             return SpGAT.inference(x, 7, n, train, drop, drop, bias_mat=graph, **kw)[0]
 
     forward(False)                                                         # creates the variables
-    opt, l2 = SpGAT.training(store.parameters(), lr=0.005, l2_coef=0.0005, capturable=args.replay)
+    opt, l2 = SpGAT.training(store.parameters(), lr=0.005, l2_coef=0.0005, capturable=args.replay, penalty_in_optimizer=True)
     stats = torch.zeros(3, device=dev)                                     # train loss, val loss, val acc
 
     def train_step():
