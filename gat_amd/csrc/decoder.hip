@@ -246,6 +246,8 @@ __global__ __launch_bounds__(64 * kGraphWaves) void ipd_bwd_graph_kernel(IpdArgs
     const float *omat = a.out_saved ? a.out_saved + b * N * (int64_t)N : nullptr;
     const bool vec = (N & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dOut) & 15) == 0 &&
                      (!a.out_saved || (reinterpret_cast<uintptr_t>(a.out_saved) & 15) == 0);
+    const bool vec2 = (N & 1) == 0 && (reinterpret_cast<uintptr_t>(a.dOut) & 7) == 0 &&
+                      (!a.out_saved || (reinterpret_cast<uintptr_t>(a.out_saved) & 7) == 0);
     for (int it = blockIdx.y * kGraphWaves + wave; it < nt; it += gridDim.y * kGraphWaves) {
         const int i0 = 16 * it;
         const bool iok = i0 + m < N;
@@ -264,6 +266,17 @@ __global__ __launch_bounds__(64 * kGraphWaves) void ipd_bwd_graph_kernel(IpdArgs
                     if (omat) {
                         const float4 o4 = *reinterpret_cast<const float4 *>(omat + irow * (uint32_t)N + jb);
                         ov[h][0] = o4.x; ov[h][1] = o4.y; ov[h][2] = o4.z; ov[h][3] = o4.w;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) gt[h][s] = gmat[(uint32_t)(jb + s) * (uint32_t)N + irow];
+                } else if (vec2 && jb + 3 < N) {          // an even number of nodes (the 246-node atlas): rows are 8-byte aligned
+                    const float2 g0 = *reinterpret_cast<const float2 *>(gmat + irow * (uint32_t)N + jb);
+                    const float2 g1 = *reinterpret_cast<const float2 *>(gmat + irow * (uint32_t)N + jb + 2);
+                    gd[h][0] = g0.x; gd[h][1] = g0.y; gd[h][2] = g1.x; gd[h][3] = g1.y;
+                    if (omat) {
+                        const float2 o0 = *reinterpret_cast<const float2 *>(omat + irow * (uint32_t)N + jb);
+                        const float2 o1 = *reinterpret_cast<const float2 *>(omat + irow * (uint32_t)N + jb + 2);
+                        ov[h][0] = o0.x; ov[h][1] = o0.y; ov[h][2] = o1.x; ov[h][3] = o1.y;
                     }
 #pragma unroll
                     for (int s = 0; s < 4; ++s) gt[h][s] = gmat[(uint32_t)(jb + s) * (uint32_t)N + irow];
