@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
     a.out += blockIdx.z * (H * FP);
     if constexpr (SAVE) { a.t2n += goff * FP; a.lse += goff; a.q += goff; }
     const float *f2b = a.f2 + b * N * (int64_t)H;
-    const bool vec = (N & 3) == 0;
+    const bool vec = (N & 3) == 0, vec2 = (N & 1) == 0 && (reinterpret_cast<uintptr_t>(a.A) & 7) == 0;
     const float maskf = (!NARROW || m < FP) ? 1.f : 0.f;
     const int mcl = (!NARROW || m < FP) ? m : 0;
 
@@ -122,6 +122,9 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
             if (vec && j < N) {
                 const float4 t4 = *reinterpret_cast<const float4 *>(arow + j);
                 av[0] = t4.x; av[1] = t4.y; av[2] = t4.z; av[3] = t4.w;
+            } else if (vec2 && j + 3 < N) {               // an even number of nodes (the 246-node atlas): 8-byte aligned rows
+                const float2 t0 = *reinterpret_cast<const float2 *>(arow + j), t1 = *reinterpret_cast<const float2 *>(arow + j + 2);
+                av[0] = t0.x; av[1] = t0.y; av[2] = t1.x; av[3] = t1.y;
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) av[t] = (j + t < N) ? arow[j + t] : 0.f;
