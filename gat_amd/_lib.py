@@ -90,7 +90,7 @@ _SIGNATURES = {
     "gatmi_masked_ce": (c_int, [c_int64, c_int32, P, c_int64, P, c_int64, P, P, P, P, P]),
     "gatmi_scale_by_device_scalar": (c_int, [P, c_int64, P, P]),
     "gatmi_bnf_attn_fwd_ws_floats": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
-    "gatmi_bnf_attn_fwd": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, c_float, P, c_int64, P, P, P, P, c_int32, P]),
+    "gatmi_bnf_attn_fwd": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, c_float, P, P, P, P, P, c_int32, P]),
     "gatmi_bnf_attn_bwd_ws_floats": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int32]),
     "gatmi_bnf_attn_bwd": (c_int, [c_int64, c_int32, c_int32, c_int32, P, P, P, P, P, P, P, P, P, P, c_float, P, P, c_int, P, P, P, P, c_int32, P]),
     "gatmi_ipd_fwd": (c_int, [c_int64, c_int32, c_int32, P, c_int32, c_float, c_uint64, P, P]),

@@ -35,7 +35,6 @@ struct BnfFwdArgs {
     float *out, *t2n, *lse, *q;
     float *uv;                  // [2][nodes][FP]: U = [A>0].X and V = A.X, written by the UV pass and read by the heads pass
     float slope;
-    int64_t ld_out;             // floats between rows of out (>= groups * H * FP): a call may fill its heads' share of wider rows
     int64_t nodes;              // B * N: group g (blockIdx.z) reads f1, f2 at + g * nodes * H, saves at + g * nodes * H (* FP)
 };
 
@@ -61,7 +60,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
     const int64_t goff = (int64_t)blockIdx.z * a.nodes * H;
     a.f1 += goff; a.f2 += goff;
     a.m1 += blockIdx.z * H; a.m2 += blockIdx.z * H;
-    a.out += blockIdx.z * (H * FP);
+    a.out += (int64_t)blockIdx.z * H * a.nodes * FP;       // out is head-major: [groups * H][nodes][FP]
     if constexpr (SAVE) { a.t2n += goff * FP; a.lse += goff; a.q += goff; }
     const float *f2b = a.f2 + b * N * (int64_t)H;
     const bool vec = (N & 3) == 0, vec2 = (N & 1) == 0 && (reinterpret_cast<uintptr_t>(a.A) & 7) == 0;
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
                     const float t2 = acc2[h][nt][r] * inv;
                     const float u = MODE == kBnfHeads ? a.uv[node * FP + c] : accU[nt][r];
                     const float v = MODE == kBnfHeads ? a.uv[(a.nodes + node) * FP + c] : accV[nt][r];
-                    a.out[node * a.ld_out + h * FP + c] = m1v[h] * (m2v[h] * u + v) + t2;
+                    a.out[(h * a.nodes + node) * FP + c] = m1v[h] * (m2v[h] * u + v) + t2;
                     if constexpr (SAVE) a.t2n[o] = t2;
                 }
             }
@@ -242,7 +241,8 @@ __global__ __launch_bounds__(256, 3) void bnf_attn_bwd_kernel(BnfBwdArgs a) {   
     const bool jok = j0 + m < N;
     {
         const int64_t g = blockIdx.z;
-        a.G += g * a.nodes * W; a.stats += g * a.nodes * (4 * H); a.f2 += g * a.nodes * H;
+        a.G += g * a.nodes * W;                      // G is head-major: [groups * H][nodes][FP]
+        a.stats += g * a.nodes * (4 * H); a.f2 += g * a.nodes * H;
         a.df1p += g * (int64_t)gridDim.y * a.nodes * H;
         a.m1 += g * H; a.m2 += g * H;
         a.dX += g * a.nodes * FP; a.dA += g * a.pairs; a.df2 += g * a.nodes * H;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 3) void bnf_attn_bwd_kernel(BnfBwdArgs a) {   
         for (int e = threadIdx.x; e < kBnfJC * (W / 2); e += 256) {
             const int r = e / (W / 2), c = e % (W / 2);
             float2 v = make_float2(0.f, 0.f);
-            if (ic + r < N) v = *reinterpret_cast<const float2 *>(a.G + (b * N + ic + r) * (int64_t)W + 2 * c);
+            if (ic + r < N) v = *reinterpret_cast<const float2 *>(a.G + (((2 * c) / FP) * a.nodes + b * N + ic + r) * (int64_t)FP + (2 * c) % FP);
             *reinterpret_cast<float2 *>(gs + r * LDG + 2 * c) = v;
         }
         for (int e = threadIdx.x; e < kBnfJC * H; e += 256) {
@@ -402,13 +402,16 @@ __global__ void bnf_dm_reduce_kernel(const float *ws, int nblocks, int width, fl
 // FP floats (q: the share of the row's softmax mass on positive logits); 64 / LP rows per wave
 template <int FP>
 __global__ __launch_bounds__(256) void bnf_row_stats_kernel(const float *G, const float *t2n, const float *f1, const float *lse,
-                                                            const float *q, float slope, int64_t rows, float *stats) {
+                                                            const float *q, float slope, int64_t rows, int64_t nodes, int H, float *stats) {
     constexpr int LP = FP / 4;                                    // lanes per row, a float4 each
     const int lane = threadIdx.x & 63;
     const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LP) + lane / LP;
     const bool ok = row < rows;
-    const int64_t o = (ok ? row : 0) * FP + 4 * (lane % LP);
-    const float4 g = *reinterpret_cast<const float4 *>(G + o), t = *reinterpret_cast<const float4 *>(t2n + o);
+    const int64_t rw = ok ? row : 0;
+    const int64_t o = rw * FP + 4 * (lane % LP);                             // t2n, f1, lse, q, stats: [group][node][head]
+    const int64_t grp = rw / (nodes * H), node = rw / H % nodes;
+    const int64_t og = ((grp * H + rw % H) * nodes + node) * FP + 4 * (lane % LP);     // G: [group][head][node]
+    const float4 g = *reinterpret_cast<const float4 *>(G + og), t = *reinterpret_cast<const float4 *>(t2n + o);
     const float c = group_sum<LP>((g.x * t.x + g.y * t.y) + (g.z * t.z + g.w * t.w));
     if (ok && lane % LP == 0) *reinterpret_cast<float4 *>(stats + row * 4) = make_float4(f1[row], lse[row], c, slope + (1.f - slope) * q[row]);
 }
@@ -446,20 +449,18 @@ extern "C" size_t gatmi_bnf_attn_fwd_ws_floats(int64_t B, int32_t N, int32_t fp,
 extern "C" int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
                                   const float *X, const float *A, const float *f1, const float *f2,
                                   const float *m1, const float *m2, float slope,
-                                  float *out, int64_t ld_out, float *t2n, float *lse, float *q, float *ws, int32_t groups, void *stream) {
+                                  float *out, float *t2n, float *lse, float *q, float *ws, int32_t groups, void *stream) {
     int rc = bnf_check(B, N, H, fp, "bnf_attn_fwd");
     if (rc) return rc;
     GATMI_REQUIRE(groups >= 1 && groups <= 1024, GATMI_EINVAL, "bnf_attn_fwd: groups must be 1..1024");
     if (B == 0 || N == 0) return GATMI_OK;
     GATMI_REQUIRE(X && A && f1 && f2 && m1 && m2 && out && (groups == 1 || ws), GATMI_EINVAL, "bnf_attn_fwd: null pointer");
-    if (ld_out == 0) ld_out = (int64_t)groups * H * fp;
-    GATMI_REQUIRE(ld_out >= (int64_t)groups * H * fp, GATMI_EINVAL, "bnf_attn_fwd: ld_out %lld is less than the %d floats of a row", (long long)ld_out, groups * H * fp);
     const bool save = t2n || lse || q;
     GATMI_REQUIRE(!save || (t2n && lse && q), GATMI_EINVAL, "bnf_attn_fwd: t2n, lse and q must be given together");
     GATMI_REQUIRE_ALIGNED(X); GATMI_REQUIRE_ALIGNED(A);
     BnfFwdArgs a;
     a.N = N; a.X = X; a.A = A; a.f1 = f1; a.f2 = f2; a.m1 = m1; a.m2 = m2;
-    a.out = out; a.t2n = t2n; a.lse = lse; a.q = q; a.uv = ws; a.slope = slope; a.ld_out = ld_out; a.nodes = B * N;
+    a.out = out; a.t2n = t2n; a.lse = lse; a.q = q; a.uv = ws; a.slope = slope; a.nodes = B * N;
     const dim3 grid((unsigned)B, (unsigned)((N + 63) / 64), (unsigned)groups);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X_(ff, hh)                                                                                  \
@@ -518,7 +519,7 @@ extern "C" int gatmi_bnf_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t fp,
 #define X_(ff, hh)                                                                         \
     if (fp == ff && H == hh) {                                                             \
         const int64_t per_block = 4 * (64 / (ff / 4));                                     \
-        hipLaunchKernelGGL(bnf_row_stats_kernel<ff>, dim3((unsigned)((rows + per_block - 1) / per_block)), dim3(256), 0, st, G, t2n, f1, lse, q, slope, rows, stats); \
+        hipLaunchKernelGGL(bnf_row_stats_kernel<ff>, dim3((unsigned)((rows + per_block - 1) / per_block)), dim3(256), 0, st, G, t2n, f1, lse, q, slope, rows, nodes, hh, stats); \
         GATMI_LAUNCH_CHECK("bnf_row_stats");                                               \
         hipLaunchKernelGGL((bnf_attn_bwd_kernel<ff, hh>), grid, dim3(256), 0, st, a);       \
         GATMI_LAUNCH_CHECK("bnf_attn_bwd");                                                \

@@ -633,7 +633,7 @@ class BnfAggregateFn(torch.autograd.Function):
         Wc = torch.einsum("fhd,shd->shf", W.reshape(F, H, Dz), a12).reshape(2 * H, F)
         f12 = torch.addmm(torch.cat([b1.reshape(H), b2.reshape(H)]), x2d, Wc.t()).reshape(n, 2, H)
         m1c, m2c = m1.reshape(H).contiguous(), m2.reshape(H).contiguous()
-        out = _new((n, H * fp), x)
+        out = _new((H, n, fp), x)                 # head-major: what the per-head convolution after it reads, and returns gradients in
         need_grad = any(ctx.needs_input_grad)
         saved = []
         for h0, hg, groups in _bnf_head_sets(H):
@@ -644,12 +644,12 @@ class BnfAggregateFn(torch.autograd.Function):
                 t2n, lse, q = _new((groups, n, hg * fp), x), _new((groups, n, hg), x), _new((groups, n, hg), x)
             wsf = _new((_lib.lib.gatmi_bnf_attn_fwd_ws_floats(B, N, fp, groups),), x) if groups > 1 else None
             _lib.call("gatmi_bnf_attn_fwd", B, N, hg, fp, ptr(xp), ptr(A), ptr(f[0]), ptr(f[1]), ptr(m1c[h0:]), ptr(m2c[h0:]), slope,
-                      ptr(out[:, h0 * fp:]), H * fp, ptr(t2n), ptr(lse), ptr(q), ptr(wsf), groups, st)
+                      ptr(out[h0:]), ptr(t2n), ptr(lse), ptr(q), ptr(wsf), groups, st)
             saved += [f, t2n, lse, q]
         if need_grad:
             ctx.dims, ctx.slope = (B, N, F, H, fp), slope
             ctx.save_for_backward(xp, A, m1c, m2c, W, a12, Wc, *saved)
-        return out.reshape(B, N, H, fp)[..., :F]
+        return out.reshape(H, B, N, fp).permute(1, 2, 0, 3)[..., :F]
 
     @staticmethod
     def backward(ctx, dout):
@@ -659,15 +659,14 @@ class BnfAggregateFn(torch.autograd.Function):
         slope = ctx.slope
         n = B * N
         st = _lib.current_stream()
-        G_all = _pad_last(_f32(dout).reshape(n, H, F), F, fp)                # [n, H, fp]
+        G_all = _pad_last(_f32(dout).permute(2, 0, 1, 3).reshape(H, n, F), F, fp)      # [H, n, fp]; no copy when the gradient arrives head-major
         dx, dA = _new((n, fp), xp), _new((B, N, N), xp)
         df12 = _new((n, 2, H), xp)
         dm = _new((2, H), xp)
         for si, (h0, hg, groups) in enumerate(_bnf_head_sets(H)):
             f, t2n, lse, q = per_set[4 * si:4 * si + 4]
             heads = groups * hg
-            # every group's rows of the incoming gradient contiguous: [groups, n, hg * fp]
-            G = G_all[:, h0:h0 + heads].reshape(n, groups, hg * fp).transpose(0, 1).contiguous()
+            G = G_all[h0:h0 + heads]
             df = _new((2, groups, n, hg), xp)                                 # df1 of every group, then df2
             dmg = _new((groups, 2, hg), xp)
             ws2 = _new((max(1, _lib.lib.gatmi_bnf_attn_bwd_ws_floats(B, N, hg, fp, groups)),), xp)

@@ -498,28 +498,27 @@ int gatmi_scale_by_device_scalar(float *x, int64_t n, const float *scale, void *
  *     out[b,i,h,:] = sum_j (m2[h]*[A_ij > 0] + A_ij) * (m1[h] + softmax_j(LeakyReLU(f1_i + f2_j))) * X[b,j,:]
  *   X [B,N,fp] (fp = feature width padded to 4, 8, 16, 32 or 64; padded columns zero), A [B,N,N],
  *   f1,f2 [B,N,H] (the logit halves of :232-233: x . (W a_s) + b_s), m1,m2 [H] in DEVICE memory, H = 1 or 2;
- *   out [B,N,H,fp], rows ld_out floats apart (0 = contiguous); t2n [B,N,H,fp] (the softmax-weighted part of out),
- *   lse and q [B,N,H] (log-sum-exp of a row's logits; the share of its softmax mass on positive logits): saved for
- *   backward, or all NULL.
+ *   out [H,B,N,fp] (head-major: the width-1 convolution that follows, :180, is a product per head, and its gradient
+ *   arrives in the same layout); t2n [B,N,H,fp] (the softmax-weighted part of out), lse and q [B,N,H] (log-sum-exp of
+ *   a row's logits; the share of its softmax mass on positive logits): saved for backward, or all NULL.
  *   groups > 1: one launch for groups x H heads of the same step (the reference runs n_heads of these steps on one
  *   input, :173; at its batch of 50 a launch for two heads fills a fraction of the chip): f1, f2, lse, q are
- *   [groups,B,N,H], t2n [groups,B,N,H,fp], m1, m2 [groups*H], and row (b,i) of out holds the groups one after
- *   the other (ld_out >= groups*H*fp); the two sums that do not depend on the head ([A>0].X and A.X) are then formed
- *   once, by a pass of their own, through ws: gatmi_bnf_attn_fwd_ws_floats(B, N, fp, groups) floats (NULL for
- *   groups = 1). */
+ *   [groups,B,N,H], t2n [groups,B,N,H,fp], m1, m2 [groups*H], out [groups*H,B,N,fp]; the two sums that do not depend
+ *   on the head ([A>0].X and A.X) are then formed once, by a pass of their own when the launch is large, through ws:
+ *   gatmi_bnf_attn_fwd_ws_floats(B, N, fp, groups) floats (NULL for groups = 1). */
 size_t gatmi_bnf_attn_fwd_ws_floats(int64_t B, int32_t N, int32_t fp, int32_t groups);
 int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
                        const float *X, const float *A, const float *f1, const float *f2,
                        const float *m1, const float *m2, float slope,
-                       float *out, int64_t ld_out, float *t2n, float *lse, float *q, float *ws, int32_t groups, void *stream);
+                       float *out, float *t2n, float *lse, float *q, float *ws, int32_t groups, void *stream);
 
-/* Backward of the above.  G [B,N,H,fp] = gradient of out (contiguous); t2n, f1, lse, q, f2 as the forward call had
- * them.  Outputs: dX [B,N,fp] (aggregation part only), dA [B,N,N], df1, df2 [B,N,H] (gradients of the logit halves:
+/* Backward of the above.  G [H,B,N,fp] = gradient of out (head-major like out); t2n, f1, lse, q, f2 as the forward
+ * call had them.  Outputs: dX [B,N,fp] (aggregation part only), dA [B,N,N], df1, df2 [B,N,H] (gradients of the logit halves:
  * df2_j = sum_i dlogit_ij; df1_i = sum_j dlogit_ij in the form sum_j C_ij n_ij <G_i, X_j> (slope_ij - mean slope of
  * row i), term by term 0 for a row whose logits lie on one side of LeakyReLU's kink),
  * dm [2H] = {dm1[H], dm2[H]}.
  * accumulate != 0: dX and dA are added to (the heads of one step share X and A).
- * groups > 1: G, t2n, f1, lse, q, f2, df1, df2 and dm carry a leading [groups] axis, m1, m2 are [groups*H]; dX and dA are
+ * groups > 1: G is [groups*H,B,N,fp]; t2n, f1, lse, q, f2, df1, df2 and dm carry a leading [groups] axis, m1, m2 are [groups*H]; dX and dA are
  * the sums over the groups (each group's share goes through ws and is added in group order).
  * ws: gatmi_bnf_attn_bwd_ws_floats(B, N, H, fp, groups) floats, 16-byte aligned. */
 size_t gatmi_bnf_attn_bwd_ws_floats(int64_t B, int32_t N, int32_t H, int32_t fp, int32_t groups);
