@@ -44,13 +44,17 @@ def test_bnf_aggregate_forward_and_gradients(B, N, F, H, Dz):
         assert_close(getattr(mod, k).grad.cpu().numpy(), rp[k].grad.numpy(), rtol=2e-5, atol_scale=1e-5, what="bnf d" + k)
 
 
-@pytest.mark.parametrize("F,out_sz,heads,residual", [(1, 16, 2, True), (8, 8, 3, False)])
+@pytest.mark.parametrize("F,out_sz,heads,residual", [(1, 16, 2, True), (8, 8, 3, False), (1, 64, 6, True)])
 def test_attn_e2v_bnf_v2_composition(F, out_sz, heads, residual):
     """attn_e2v_BNF_V2 (utils/layers.py:158-227): five rounds of attention heads on the kernels with
-    the reference's dense layers around them, against the float64 restatement with the same weights."""
+    the reference's dense layers around them, against the float64 restatement with the same weights.
+    The last case has BNF_AE.py's widths (six heads of 64) and enough node rows for the dense layers'
+    parameter gradients to come from the library's row-split reductions."""
     from gat_amd.layers import AttnE2VBNFV2
+    from gat_amd import ops
     dev = torch.device("cuda:0")
-    B, N = 3, 50
+    B, N = (3, 50) if heads < 6 else (12, 90)
+    assert (B * N >= ops.TALL_LINEAR_ROWS) == (heads == 6)
     rng = np.random.default_rng(F)
     x = rng.normal(0, 1, (B, N, F))
     A = rng.random((B, N, N)) * (rng.random((B, N, N)) < 0.2)
@@ -60,6 +64,9 @@ def test_attn_e2v_bnf_v2_composition(F, out_sz, heads, residual):
     with torch.no_grad():
         for att in mod.att:                      # non-trivial logit biases and scalars
             att.b1.normal_(0, 0.1); att.b2.normal_(0, 0.1); att.m1.add_(torch.randn_like(att.m1) * 0.1); att.m2.add_(torch.randn_like(att.m2) * 0.1)
+        if heads == 6:                           # six heads of 64 at the default initialisation grow to 6e4 over the five rounds
+            for w in mod.head_w:
+                w.mul_(0.2)
     xt = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
     At = torch.tensor(A, dtype=torch.float32, device=dev)
     out, aggall = mod(xt, At)
@@ -77,13 +84,21 @@ def test_attn_e2v_bnf_v2_composition(F, out_sz, heads, residual):
     rout, ragg = ref_torch.attn_e2v_bnf_v2(rx, torch.tensor(A), rounds, (d(mod.out1.weight.t()), d(mod.out1.bias)),
                                            (d(mod.out2.weight.t()), d(mod.out2.bias)), "relu", residual)
     assert_close(aggall.detach().cpu().numpy(), ragg.detach().numpy(), rtol=2e-5, atol_scale=1e-5, what="e2v aggall")
-    assert_close(out.detach().cpu().numpy(), rout.detach().numpy(), rtol=2e-5, atol_scale=1e-5, what="e2v out")
+    # out is normalised over the nodes per column; with 64 columns some keep a handful of non-zero nodes after the
+    # ReLUs and a small norm, which magnifies the fp32 error of the dense layers before it
+    wide = heads == 6
+    assert_close(out.detach().cpu().numpy(), rout.detach().numpy(), rtol=2e-4 if wide else 2e-5, atol_scale=1e-4 if wide else 1e-5, what="e2v out")
     g = rng.normal(0, 1, tuple(aggall.shape))
     aggall.backward(torch.tensor(g, dtype=torch.float32, device=dev))
     ragg.backward(torch.tensor(g))
-    assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), rtol=1e-4, atol_scale=5e-5, what="e2v dX")
-    assert_close(mod.att[0].W.grad.cpu().numpy(), rounds[0]["W"].grad.numpy(), rtol=1e-4, atol_scale=5e-5, what="e2v dW(repetition 0)")
-    assert_close(mod.att[4].m1.grad.cpu().numpy(), rounds[4]["m1"].grad.numpy(), rtol=1e-4, atol_scale=5e-5, what="e2v dm1(repetition 4)")
+    gr, ga = (3e-4, 1.5e-4) if wide else (1e-4, 5e-5)       # five rounds deep: the wide case accumulates three times the error
+    assert_close(xt.grad.cpu().numpy(), rx.grad.numpy(), rtol=gr, atol_scale=ga, what="e2v dX")
+    assert_close(mod.att[0].W.grad.cpu().numpy(), rounds[0]["W"].grad.numpy(), rtol=gr, atol_scale=ga, what="e2v dW(repetition 0)")
+    assert_close(mod.att[4].m1.grad.cpu().numpy(), rounds[4]["m1"].grad.numpy(), rtol=gr, atol_scale=ga, what="e2v dm1(repetition 4)")
+    assert_close(mod.merge[1].weight.grad.t().cpu().numpy(), rounds[1]["merge_w"].grad.numpy(), rtol=gr, atol_scale=ga, what="e2v d merge_w(repetition 1)")
+    assert_close(mod.merge[1].bias.grad.cpu().numpy(), rounds[1]["merge_b"].grad.numpy(), rtol=gr, atol_scale=ga, what="e2v d merge_b(repetition 1)")
+    assert_close(mod.head_b[2].grad.cpu().numpy(), rounds[2]["head_b"].grad.numpy(), rtol=gr, atol_scale=ga, what="e2v d head_b(repetition 2)")
+    assert_close(mod.head_w[2].grad.cpu().numpy(), rounds[2]["head_w"].grad.numpy(), rtol=gr, atol_scale=ga, what="e2v d head_w(repetition 2)")
 
 
 def test_gat_ae_bnf_v2_model_runs_on_the_kernels():
