@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
     a.f1 += goff; a.f2 += goff;
     a.m1 += blockIdx.z * H; a.m2 += blockIdx.z * H;
     a.out += (int64_t)blockIdx.z * H * a.nodes * FP;       // out is head-major: [groups * H][nodes][FP]
-    if constexpr (SAVE) { a.t2n += goff * FP; a.lse += goff; a.q += goff; }
+    if constexpr (SAVE) { a.t2n += goff * FP; a.lse += goff; a.q += 2 * goff; }
     const float *f2b = a.f2 + b * N * (int64_t)H;
     const bool vec = (N & 3) == 0, vec2 = (N & 1) == 0 && (reinterpret_cast<uintptr_t>(a.A) & 7) == 0;
     const float maskf = (!NARROW || m < FP) ? 1.f : 0.f;
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
                 for (int h = 0; MODE != kBnfUV && h < H; ++h) {
                     const float z = f1v[h] + f2s[(jl + 4 * kq + t) * H + h];     // -inf for j >= N => p = 0
                     const float p = exp_neg(leaky(z, a.slope) - mx[h]);
-                    ssum[h] += p;
-                    if constexpr (SAVE) qsum[h] += z > 0.f ? p : 0.f;
+                    ssum[h] += z > 0.f ? 0.f : p;            // the mass on negative logits; qsum: on positive ones
+                    qsum[h] += z > 0.f ? p : 0.f;
                     const float np_ = (m2v[h] * th + av[t]) * p;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc2[h][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(np_, xr[nt], acc2[h][nt], 0, 0, 0);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         ssum[h] += __shfl_xor(ssum[h], 16, 64); ssum[h] += __shfl_xor(ssum[h], 32, 64);
-        if constexpr (SAVE) { qsum[h] += __shfl_xor(qsum[h], 16, 64); qsum[h] += __shfl_xor(qsum[h], 32, 64); }
+        qsum[h] += __shfl_xor(qsum[h], 16, 64); qsum[h] += __shfl_xor(qsum[h], 32, 64);
     }
     // C layout: lane (kq, m) holds rows 4*kq + r, column 16*nt + m
 #pragma unroll
@@ -183,16 +183,18 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = i0 + 4 * kq + r;
-            const float s = __shfl(ssum[h], 4 * kq + r, 64);
+            const float sneg = __shfl(ssum[h], 4 * kq + r, 64), qv = __shfl(qsum[h], 4 * kq + r, 64);
+            const float s = sneg + qv;
             const float mrow = __shfl(mx[h], 4 * kq + r, 64);
-            const float qv = SAVE ? __shfl(qsum[h], 4 * kq + r, 64) : 0.f;
             const float inv = s > 0.f ? 1.0f / s : 0.f;
             if (i >= N) continue;
             const int64_t node = b * N + i;
             if constexpr (SAVE) {
                 if (m == 0) {
                     a.lse[node * H + h] = mrow + logf(s);
-                    a.q[node * H + h] = qv * inv;      // share of the row's softmax mass that lies on positive logits
+                    // the shares of the row's softmax mass on positive and on negative logits, each from its own sum: the
+                    // small one of the two keeps its relative precision (1 - the other would not)
+                    *reinterpret_cast<float2 *>(a.q + (node * H + h) * 2) = make_float2(qv * inv, sneg * inv);
                 }
             }
 #pragma unroll
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void bnf_attn_fwd_kernel(BnfFwdArgs a) {
 
 struct BnfBwdArgs {
     int N;
-    const float *G, *stats, *X, *A, *f2, *m1, *m2;    // stats [nodes, H] x {f1, lse, c, mean slope}
+    const float *G, *stats, *q, *X, *A, *f2, *m1, *m2; // stats [nodes, H] x {f1, lse, c, positive share}; q [nodes, H] x {positive, negative share}
     float *dX, *dA, *df1p, *df2, *ws;                  // df1p [source blocks][nodes, H]: every block's share of df1
     float slope;
     int accumulate;             // dX, dA: add to what is there (a later group of heads of the same step)
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(256, 3) void bnf_attn_bwd_kernel(BnfBwdArgs a) {   
     __shared__ __attribute__((aligned(16))) float gs[kBnfJC * LDG];       // G rows (all heads) of the destination chunk
     __shared__ __attribute__((aligned(16))) float ss[kBnfJC * H * 4];     // {f1, lse, c, -}
     __shared__ float red[4][2 * H];
+    __shared__ float sn[kBnfJC * H];                                       // negative-logit share of the chunk's rows
     __shared__ float p1[4][kBnfJC * H];                                    // every wave's share of df1 for the chunk's rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(256, 3) void bnf_attn_bwd_kernel(BnfBwdArgs a) {   
     {
         const int64_t g = blockIdx.z;
         a.G += g * a.nodes * W;                      // G is head-major: [groups * H][nodes][FP]
+        a.q += g * a.nodes * (2 * H);
         a.stats += g * a.nodes * (4 * H); a.f2 += g * a.nodes * H;
         a.df1p += g * (int64_t)gridDim.y * a.nodes * H;
         a.m1 += g * H; a.m2 += g * H;
@@ -275,8 +279,13 @@ __global__ __launch_bounds__(256, 3) void bnf_attn_bwd_kernel(BnfBwdArgs a) {   
         }
         for (int e = threadIdx.x; e < kBnfJC * H; e += 256) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ic + e / H < N) v = *reinterpret_cast<const float4 *>(a.stats + ((b * N + ic) * (int64_t)H + e) * 4);
+            float qn = 0.f;
+            if (ic + e / H < N) {
+                v = *reinterpret_cast<const float4 *>(a.stats + ((b * N + ic) * (int64_t)H + e) * 4);
+                qn = a.q[((b * N + ic) * (int64_t)H + e) * 2 + 1];
+            }
             *reinterpret_cast<float4 *>(ss + e * 4) = v;
+            sn[e] = qn;
         }
         for (int e = threadIdx.x; e < 4 * kBnfJC * H; e += 256) (&p1[0][0])[e] = 0.f;
         __syncthreads();
@@ -316,10 +325,11 @@ __global__ __launch_bounds__(256, 3) void bnf_attn_bwd_kernel(BnfBwdArgs a) {   
                     const float cnd = C * n * D[r];                                            // 0 where !ok: C = 0
                     const float sp = z > 0.f ? 1.f : a.slope;
                     df2[h] += (cnd - C * st.z) * sp;
-                    // df1_i = sum_j C (n D - c_i) sp with c_i = sum_j C n D  =  sum_j C n D (sp_ij - mean slope of row i): each
-                    // term is exactly 0 in a row whose logits all lie on one side of the kink, and no c_i from another
-                    // summation order enters.  Summed over the wave's 16 sources here.
-                    const float rowsum = group_sum<16>(cnd * (sp - st.w));
+                    // df1_i = sum_j C (n D - c_i) sp with c_i = sum_j C n D  =  (1 - slope) (qneg_i sum_{z > 0} C n D - qpos_i
+                    // sum_{z <= 0} C n D): term by term 0 in a row whose logits all lie on one side of the kink, no c_i from
+                    // another summation order, and the small share of a nearly one-sided row at full relative precision.
+                    // Summed over the wave's 16 sources here.
+                    const float rowsum = (1.f - a.slope) * group_sum<16>(cnd * (z > 0.f ? sn[(il + 4 * kq + r) * H + h] : -st.w));
                     if (m == 0) p1[wave][(il + 4 * kq + r) * H + h] = rowsum;
                 }
 #pragma unroll
@@ -398,8 +408,8 @@ __global__ void bnf_dm_reduce_kernel(const float *ws, int nblocks, int width, fl
     if (ok && threadIdx.y == 0) out[c] = t;
 }
 
-// stats[row] = {f1, lse, c = <G_row, t2n_row>, mean slope = slope + (1 - slope) q} for every (group, node, head) row of
-// FP floats (q: the share of the row's softmax mass on positive logits); 64 / LP rows per wave
+// stats[row] = {f1, lse, c = <G_row, t2n_row>, the share of the row's softmax mass on positive logits} for every
+// (group, node, head) row of FP floats; 64 / LP rows per wave
 template <int FP>
 __global__ __launch_bounds__(256) void bnf_row_stats_kernel(const float *G, const float *t2n, const float *f1, const float *lse,
                                                             const float *q, float slope, int64_t rows, int64_t nodes, int H, float *stats) {
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(256) void bnf_row_stats_kernel(const float *G, cons
     const int64_t og = ((grp * H + rw % H) * nodes + node) * FP + 4 * (lane % LP);     // G: [group][head][node]
     const float4 g = *reinterpret_cast<const float4 *>(G + og), t = *reinterpret_cast<const float4 *>(t2n + o);
     const float c = group_sum<LP>((g.x * t.x + g.y * t.y) + (g.z * t.z + g.w * t.w));
-    if (ok && lane % LP == 0) *reinterpret_cast<float4 *>(stats + row * 4) = make_float4(f1[row], lse[row], c, slope + (1.f - slope) * q[row]);
+    if (ok && lane % LP == 0) *reinterpret_cast<float4 *>(stats + row * 4) = make_float4(f1[row], lse[row], c, q[2 * row]);
 }
 
 // dst[e] (+)= sum over groups of part[g][e], in group order; blockIdx.y: one such sum per slab of part and dst
@@ -509,7 +519,7 @@ extern "C" int gatmi_bnf_attn_bwd(int64_t B, int32_t N, int32_t H, int32_t fp,
     float *dmws = df1p + (size_t)groups * jb * nodes * H;
     float *part = dmws + (size_t)nblocks * (2 * H) * groups;               // [groups][dX] then [groups][dA]
     BnfBwdArgs a;
-    a.N = N; a.G = G; a.stats = stats; a.X = X; a.A = A; a.f2 = f2; a.m1 = m1; a.m2 = m2;
+    a.N = N; a.G = G; a.stats = stats; a.q = q; a.X = X; a.A = A; a.f2 = f2; a.m1 = m1; a.m2 = m2;
     a.dX = dX; a.dA = dA; a.df1p = df1p; a.df2 = df2; a.ws = dmws; a.slope = slope; a.accumulate = accumulate;
     a.nodes = nodes; a.pairs = pairs;
     if (groups > 1) { a.dX = part; a.dA = part + (size_t)groups * nodes * fp; a.accumulate = 0; }

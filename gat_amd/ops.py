@@ -641,7 +641,7 @@ class BnfAggregateFn(torch.autograd.Function):
             f = f12[:, :, h0:h0 + groups * hg].reshape(n, 2, groups, hg).permute(1, 2, 0, 3).contiguous()
             t2n = lse = q = None
             if need_grad:
-                t2n, lse, q = _new((groups, n, hg * fp), x), _new((groups, n, hg), x), _new((groups, n, hg), x)
+                t2n, lse, q = _new((groups, n, hg * fp), x), _new((groups, n, hg), x), _new((groups, n, hg, 2), x)
             wsf = _new((_lib.lib.gatmi_bnf_attn_fwd_ws_floats(B, N, fp, groups),), x) if groups > 1 else None
             _lib.call("gatmi_bnf_attn_fwd", B, N, hg, fp, ptr(xp), ptr(A), ptr(f[0]), ptr(f[1]), ptr(m1c[h0:]), ptr(m2c[h0:]), slope,
                       ptr(out[h0:]), ptr(t2n), ptr(lse), ptr(q), ptr(wsf), groups, st)

@@ -499,11 +499,12 @@ int gatmi_scale_by_device_scalar(float *x, int64_t n, const float *scale, void *
  *   X [B,N,fp] (fp = feature width padded to 4, 8, 16, 32 or 64; padded columns zero), A [B,N,N],
  *   f1,f2 [B,N,H] (the logit halves of :232-233: x . (W a_s) + b_s), m1,m2 [H] in DEVICE memory, H = 1 or 2;
  *   out [H,B,N,fp] (head-major: the width-1 convolution that follows, :180, is a product per head, and its gradient
- *   arrives in the same layout); t2n [B,N,H,fp] (the softmax-weighted part of out), lse and q [B,N,H] (log-sum-exp of
- *   a row's logits; the share of its softmax mass on positive logits): saved for backward, or all NULL.
+ *   arrives in the same layout); t2n [B,N,H,fp] (the softmax-weighted part of out), lse [B,N,H] (log-sum-exp of a
+ *   row's logits) and q [B,N,H,2] (the shares of its softmax mass on positive and on negative logits): saved for
+ *   backward, or all NULL.
  *   groups > 1: one launch for groups x H heads of the same step (the reference runs n_heads of these steps on one
- *   input, :173; at its batch of 50 a launch for two heads fills a fraction of the chip): f1, f2, lse, q are
- *   [groups,B,N,H], t2n [groups,B,N,H,fp], m1, m2 [groups*H], out [groups*H,B,N,fp]; the two sums that do not depend
+ *   input, :173; at its batch of 50 a launch for two heads fills a fraction of the chip): f1, f2, lse are
+ *   [groups,B,N,H], q [groups,B,N,H,2], t2n [groups,B,N,H,fp], m1, m2 [groups*H], out [groups*H,B,N,fp]; the two sums that do not depend
  *   on the head ([A>0].X and A.X) are then formed once, by a pass of their own when the launch is large, through ws:
  *   gatmi_bnf_attn_fwd_ws_floats(B, N, fp, groups) floats (NULL for groups = 1). */
 size_t gatmi_bnf_attn_fwd_ws_floats(int64_t B, int32_t N, int32_t fp, int32_t groups);
@@ -514,8 +515,8 @@ int gatmi_bnf_attn_fwd(int64_t B, int32_t N, int32_t H, int32_t fp,
 
 /* Backward of the above.  G [H,B,N,fp] = gradient of out (head-major like out); t2n, f1, lse, q, f2 as the forward
  * call had them.  Outputs: dX [B,N,fp] (aggregation part only), dA [B,N,N], df1, df2 [B,N,H] (gradients of the logit halves:
- * df2_j = sum_i dlogit_ij; df1_i = sum_j dlogit_ij in the form sum_j C_ij n_ij <G_i, X_j> (slope_ij - mean slope of
- * row i), term by term 0 for a row whose logits lie on one side of LeakyReLU's kink),
+ * df2_j = sum_i dlogit_ij; df1_i = sum_j dlogit_ij in the form (1 - slope)(qneg_i sum_{z>0} - qpos_i sum_{z<=0}) of
+ * C_ij n_ij <G_i, X_j>, term by term 0 for a row whose logits lie on one side of LeakyReLU's kink),
  * dm [2H] = {dm1[H], dm2[H]}.
  * accumulate != 0: dX and dA are added to (the heads of one step share X and A).
  * groups > 1: G is [groups*H,B,N,fp]; t2n, f1, lse, q, f2, df1, df2 and dm carry a leading [groups] axis, m1, m2 are [groups*H]; dX and dA are

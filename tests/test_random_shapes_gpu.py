@@ -260,9 +260,10 @@ def test_decoder_and_bnf_random_draw(seed):
         z = (x.reshape(B, N, F) @ p["W"].reshape(F, H * Dz)).reshape(B, N, H, Dz)
         zf1 = (z * p["a1"]).sum(-1) + p["b1"]
         zf2 = (z * p["a2"]).sum(-1) + p["b2"]
-        return float(np.abs(zf1[:, :, None, :] + zf2[:, None, :, :]).min())
+        zz = np.abs(zf1[:, :, None, :] + zf2[:, None, :, :])
+        return float(zz.min()), float(zz.max())
     for _ in range(50):
-        if min_abs_logit(x) > KINK:
+        if min_abs_logit(x)[0] > KINK:
             break
         x = rng.normal(0, 1, (B, N, F))
     mod = BNFAttention(F, H, Dz, device=dev)
@@ -278,7 +279,7 @@ def test_decoder_and_bnf_random_draw(seed):
     rA = torch.tensor(A, dtype=torch.float64, requires_grad=True)
     ref = ref_torch.bnf_v2e_aggregate(rx, rA, rp)
     assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), what=what + " forward")
-    if min_abs_logit(x) <= KINK:
+    if min_abs_logit(x)[0] <= KINK:
         pytest.skip("fifty redraws all left a logit within fp32 rounding of LeakyReLU's kink")
     dout = rng.normal(0, 1, tuple(ref.shape))
     out.backward(torch.tensor(dout, dtype=torch.float32, device=dev))
@@ -289,7 +290,12 @@ def test_decoder_and_bnf_random_draw(seed):
     # features) that cancel to something often a hundred times smaller (zero where a row's logits all lie on one side
     # of LeakyReLU's kink, which the kernel's form of the sum reproduces term by term): its fp32 error is absolute,
     # ~1e-7 of those terms per node, and dW / da1 inherit it.  Band: 1e-4 relative + 3e-5 absolute for unit-scale inputs.
+    # With wide features the drawn logits reach |z| of 40 and more: the softmax is then one-hot in fp32 terms, the
+    # gradient of a logit is a difference of two numbers that agree to six digits (n D_ij - c_i for the one source j
+    # that holds the row's mass), and the exponent's own rounding error grows with |z|: the absolute part of the
+    # band grows with the largest logit beyond 8.
+    spread = max(1.0, min_abs_logit(x)[1] / 8.0)
     for k in ("W", "a1", "a2", "m1", "m2"):
         got, want = getattr(mod, k).grad.cpu().numpy().astype(np.float64), rp[k].grad.numpy()
-        tol = 1e-4 * np.abs(want) + 1e-4 * np.abs(want).max() + 3e-5
+        tol = 1e-4 * np.abs(want) + 1e-4 * np.abs(want).max() + 3e-5 * spread
         assert (np.abs(got - want) <= tol).all(), "%s d%s: worst %.3g of the band" % (what, k, (np.abs(got - want) / tol).max())
