@@ -367,7 +367,7 @@ constexpr int kMaskBatch = 6;      // 16-source steps whose mask loads are issue
 constexpr int kMaskBatchBwd = 1;   // 16-destination steps whose mask loads are issued together (backward)
 
 template <int H, int DP, bool SAVE, bool DROP>
-__global__ __launch_bounds__(256) void dense_attn_fwd_hg_kernel(DenseFwdArgs a) {
+__global__ __launch_bounds__(256, 5) void dense_attn_fwd_hg_kernel(DenseFwdArgs a) {      // five waves per SIMD (at most 96 registers): 2.45 -> 2.24 ms at 4096 x 264
     using S = WaveSplit<H>;
     constexpr int HPW = S::HPW;
     constexpr int HD = H * DP;
