@@ -41,6 +41,8 @@ _SIGNATURES = {
     "gatmi_proj_bwd_ws_floats": (c_size_t, [c_int32, c_int32, c_int32]),
     "gatmi_proj_bwd_params": (c_int, [P, c_int64, c_int32, c_int64, P, P, P, P, c_int32, c_int32, P, P, P, P, P, P, c_float, c_uint64, P]),
     "gatmi_proj_bwd_input": (c_int, [P, c_int64, c_int32, P, c_int32, c_int32, P, c_int64, c_int, c_float, c_uint64, P]),
+    "gatmi_bias_act_fwd": (c_int, [P, c_int64, c_int32, c_int64, P, c_int32, P, P]),
+    "gatmi_bias_act_bwd": (c_int, [P, P, c_int64, c_int32, c_int64, c_int32, P, P, P, P]),
     "gatmi_column_sums_ws_floats": (c_size_t, [c_int64, c_int32]),
     "gatmi_column_sums": (c_int, [P, c_int64, c_int32, c_int64, P, P, P]),
     "gatmi_linear_bwd_ws_floats": (c_size_t, [c_int64, c_int32, c_int32]),

@@ -851,6 +851,74 @@ __global__ void column_total_kernel(const float *ws, int nblocks, int width, flo
     if (ok && threadIdx.y == 0) out[c] = t;
 }
 
+// Y = act(X + b) for every row of X [n, w] (rows ld floats apart in both): the bias and activation of a width-1
+// convolution (tf.layers.conv1d(., w, 1, activation), utils/layers.py:180,183,223-224) in one pass.
+template <int ACT>
+__device__ __forceinline__ float bias_act_value(float v) {
+    if constexpr (ACT == GATMI_ACT_RELU) return fmaxf(v, 0.f);
+    if constexpr (ACT == GATMI_ACT_ELU) return v > 0.f ? v : __expf(v) - 1.f;
+    return v;
+}
+// the activation's derivative from its OUTPUT y (ReLU: [y > 0]; ELU: 1 for y > 0, y + 1 otherwise)
+template <int ACT>
+__device__ __forceinline__ float bias_act_slope(float y) {
+    if constexpr (ACT == GATMI_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if constexpr (ACT == GATMI_ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
+    return 1.f;
+}
+
+// four columns per thread: w, ld multiples of 4 and 16-byte aligned pointers
+template <int ACT>
+__global__ __launch_bounds__(256) void bias_act_fwd4_kernel(const float *X, int64_t n, int w4, int64_t ld, const float *b, float *Y) {
+    const int64_t total = n * w4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / w4;
+        const int c = 4 * (int)(e - r * w4);
+        const float4 v = *reinterpret_cast<const float4 *>(X + r * ld + c), bb = *reinterpret_cast<const float4 *>(b + c);
+        *reinterpret_cast<float4 *>(Y + r * ld + c) = make_float4(bias_act_value<ACT>(v.x + bb.x), bias_act_value<ACT>(v.y + bb.y),
+                                                                 bias_act_value<ACT>(v.z + bb.z), bias_act_value<ACT>(v.w + bb.w));
+    }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float *X, int64_t n, int w, int64_t ld, const float *b, float *Y) {
+    const int64_t total = n * w;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / w;
+        const int c = (int)(e - r * w);
+        Y[r * ld + c] = bias_act_value<ACT>(X[r * ld + c] + b[c]);
+    }
+}
+
+// dPre = dY * act'(Y) and, in the same pass, every row block's column sums of dPre (the bias gradient): the shape of
+// column_partial_kernel with the product formed and stored on the way.  ws[b][width].
+template <int ACT>
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *dY, const float *Y, int64_t n, int width, int64_t ld,
+                                                           float *dPre, float *ws) {
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + tx;
+    const bool ok = c < width;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t col = ok ? c : 0;
+    for (int64_t r = r0 + ty; r < r1; r += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t o = (r + 4 * u) * ld + col;
+            if (ok && r + 4 * u < r1) {
+                const float v = dY[o] * bias_act_slope<ACT>(Y[o]);
+                dPre[o] = v;
+                s[u] += v;
+            }
+        }
+    }
+    part[ty][tx] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (ty == 0 && ok) ws[(int64_t)blockIdx.x * width + c] = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+}
+
 static unsigned column_sum_blocks(int64_t n) { return (unsigned)std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 63) / 64)); }
 
 // preprocess_features (utils/process.py:155-162) for a CSR matrix: out = val / rowsum, rows that
@@ -1072,6 +1140,53 @@ extern "C" int gatmi_linear_bwd_params(const float *X, int64_t n, int32_t f_in, 
     const unsigned nb = column_sum_blocks(n);
     hipLaunchKernelGGL(column_partial_kernel, dim3(nb, (unsigned)((w + 63) / 64)), dim3(256), 0, st, dY, n, w, (int64_t)w, ws);
     GATMI_LAUNCH_CHECK("column_partial");
+    hipLaunchKernelGGL(column_total_kernel, dim3((unsigned)((w + kSumCols - 1) / kSumCols)), dim3(kSumCols, kSumRows), 0, st, ws, (int)nb, w, db);
+    GATMI_LAUNCH_CHECK("column_total");
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_bias_act_fwd(const float *X, int64_t n, int32_t w, int64_t ld, const float *b, int32_t activation,
+                                  float *Y, void *stream) {
+    GATMI_REQUIRE(n >= 0 && w > 0 && ld >= w, GATMI_EINVAL, "bias_act_fwd: bad dims");
+    GATMI_REQUIRE(X && b && Y, GATMI_EINVAL, "bias_act_fwd: null pointer");
+    if (n == 0) return GATMI_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (w % 4 == 0 && ld % 4 == 0 && aligned16(X) && aligned16(Y) && aligned16(b)) {
+        const unsigned nb4 = (unsigned)std::min<int64_t>(4096, (n * (w / 4) + 255) / 256);
+        switch (activation) {
+            case GATMI_ACT_RELU: hipLaunchKernelGGL(bias_act_fwd4_kernel<GATMI_ACT_RELU>, dim3(nb4), dim3(256), 0, st, X, n, w / 4, ld, b, Y); break;
+            case GATMI_ACT_ELU: hipLaunchKernelGGL(bias_act_fwd4_kernel<GATMI_ACT_ELU>, dim3(nb4), dim3(256), 0, st, X, n, w / 4, ld, b, Y); break;
+            case GATMI_ACT_IDENTITY: hipLaunchKernelGGL(bias_act_fwd4_kernel<GATMI_ACT_IDENTITY>, dim3(nb4), dim3(256), 0, st, X, n, w / 4, ld, b, Y); break;
+            default: return fail(GATMI_EUNSUPPORTED, "bias_act_fwd: activation %d (identity, elu or relu)", activation);
+        }
+        GATMI_LAUNCH_CHECK("bias_act_fwd");
+        return GATMI_OK;
+    }
+    const unsigned nb = (unsigned)std::min<int64_t>(4096, (n * w + 255) / 256);
+    switch (activation) {
+        case GATMI_ACT_RELU: hipLaunchKernelGGL(bias_act_fwd_kernel<GATMI_ACT_RELU>, dim3(nb), dim3(256), 0, st, X, n, w, ld, b, Y); break;
+        case GATMI_ACT_ELU: hipLaunchKernelGGL(bias_act_fwd_kernel<GATMI_ACT_ELU>, dim3(nb), dim3(256), 0, st, X, n, w, ld, b, Y); break;
+        case GATMI_ACT_IDENTITY: hipLaunchKernelGGL(bias_act_fwd_kernel<GATMI_ACT_IDENTITY>, dim3(nb), dim3(256), 0, st, X, n, w, ld, b, Y); break;
+        default: return fail(GATMI_EUNSUPPORTED, "bias_act_fwd: activation %d (identity, elu or relu)", activation);
+    }
+    GATMI_LAUNCH_CHECK("bias_act_fwd");
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_bias_act_bwd(const float *dY, const float *Y, int64_t n, int32_t w, int64_t ld, int32_t activation,
+                                  float *dPre, float *db, float *ws, void *stream) {
+    GATMI_REQUIRE(n >= 0 && w > 0 && ld >= w, GATMI_EINVAL, "bias_act_bwd: bad dims");
+    GATMI_REQUIRE(dY && Y && dPre && db && ws, GATMI_EINVAL, "bias_act_bwd: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned nb = column_sum_blocks(n);
+    const dim3 grid(nb, (unsigned)((w + 63) / 64));
+    switch (activation) {
+        case GATMI_ACT_RELU: hipLaunchKernelGGL(bias_act_bwd_kernel<GATMI_ACT_RELU>, grid, dim3(256), 0, st, dY, Y, n, w, ld, dPre, ws); break;
+        case GATMI_ACT_ELU: hipLaunchKernelGGL(bias_act_bwd_kernel<GATMI_ACT_ELU>, grid, dim3(256), 0, st, dY, Y, n, w, ld, dPre, ws); break;
+        case GATMI_ACT_IDENTITY: hipLaunchKernelGGL(bias_act_bwd_kernel<GATMI_ACT_IDENTITY>, grid, dim3(256), 0, st, dY, Y, n, w, ld, dPre, ws); break;
+        default: return fail(GATMI_EUNSUPPORTED, "bias_act_bwd: activation %d (identity, elu or relu)", activation);
+    }
+    GATMI_LAUNCH_CHECK("bias_act_bwd");
     hipLaunchKernelGGL(column_total_kernel, dim3((unsigned)((w + kSumCols - 1) / kSumCols)), dim3(kSumCols, kSumRows), 0, st, ws, (int)nb, w, db);
     GATMI_LAUNCH_CHECK("column_total");
     return GATMI_OK;

@@ -352,11 +352,12 @@ def InnerProductDecoder(seq, activation="sigmoid", dropout=0.0):
     return ops.inner_product_decoder(seq, activation, dropout).reshape(-1)
 
 
-def _linear(layer, x):
-    """A width-1 convolution of the reference (tf.layers.conv1d(x, out, 1)) held as torch.nn.Linear, or the identity."""
+def _linear(layer, x, activation="identity"):
+    """A width-1 convolution of the reference (tf.layers.conv1d(x, out, 1, activation)) held as torch.nn.Linear, or the
+    identity."""
     if isinstance(layer, nn.Identity):
         return x
-    return ops.tall_linear(x, layer.weight, layer.bias)
+    return ops.tall_linear(x, layer.weight, layer.bias, activation)
 
 
 class AttnE2VBNFV2(nn.Module):
@@ -387,24 +388,19 @@ class AttnE2VBNFV2(nn.Module):
         self.out1 = nn.Linear(reps * out_sz, out_sz, **kw)
         self.out2 = nn.Linear(out_sz, out_sz, **kw)
 
-    def _act(self, x):
-        if self.activation == "relu":
-            return torch.relu(x)
-        return torch.nn.functional.elu(x) if self.activation == "elu" else x
-
     def forward(self, seq, net_mat):
         seq_out, outs = seq, []
         for rep in range(self.reps):
             agg = self.att[rep](seq_out, net_mat)                                        # [B,N,H,F]   layers.py:174-179
             heads = torch.einsum("bnhf,hfo->bnho", agg, self.head_w[rep])
-            heads = self._act(ops.add_row_bias(heads.flatten(2), self.head_b[rep].reshape(-1))).unflatten(2, self.head_b[rep].shape)   # :180
-            merged = self._act(_linear(self.merge[rep], heads.flatten(2)))              # :182-183
+            heads = ops.add_row_bias(heads.flatten(2), self.head_b[rep].reshape(-1), self.activation)         # :180
+            merged = _linear(self.merge[rep], heads, self.activation)                    # :182-183
             if self.residual:
                 seq_out = merged + _linear(self.res[rep], seq_out)                      # :185-189
             else:
                 seq_out = merged
             outs.append(seq_out)
         aggall = torch.cat(outs, dim=-1)
-        out = self._act(_linear(self.out2, self._act(_linear(self.out1, aggall))))
+        out = _linear(self.out2, _linear(self.out1, aggall, self.activation), self.activation)
         out = out / torch.sqrt(torch.clamp((out * out).sum(dim=-2, keepdim=True), min=1e-12))   # tf.nn.l2_normalize(axis=-2)
         return out, aggall

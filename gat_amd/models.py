@@ -320,7 +320,7 @@ class GAT_AE_BNF_V2(torch.nn.Module):
         graph = layers.InnerProductDecoder(emb).reshape(-1, N, N)
         if training:
             emb = torch.nn.functional.dropout(emb, 0.3, True)
-        return torch.relu(layers._linear(self.node_fc1[k], emb)), graph
+        return layers._linear(self.node_fc1[k], emb, "relu"), graph
 
     def forward(self, inputs, net_mat, training=False):
         """inputs [B,N,F], net_mat [B,N,N] -> (digits [B,C], reconstruct_fmri [B,N,N],
@@ -328,7 +328,7 @@ class GAT_AE_BNF_V2(torch.nn.Module):
         returns the same five values."""
         fc_a, rec_a = self._reconstruction(0, inputs, net_mat, training)
         fc_b, rec_b = self._reconstruction(1, inputs, net_mat, training)
-        node_fc2 = torch.relu(layers._linear(self.node_fc2, torch.cat([fc_a, fc_b], dim=-1)))
+        node_fc2 = layers._linear(self.node_fc2, torch.cat([fc_a, fc_b], dim=-1), "relu")
         digits = self.dense_out(node_fc2.mean(dim=-2))
         cam = node_fc2 @ self.dense_out.weight.t()
         return digits, rec_a, rec_b, torch.softmax(digits, dim=-1), cam

@@ -690,87 +690,127 @@ def bnf_aggregate(x, net_mat, W, a1, a2, b1, b2, m1, m2, slope=LEAKY_SLOPE):
     return BnfAggregateFn.apply(x, net_mat, W, a1, a2, b1, b2, m1, m2, float(slope))
 
 
+_DENSE_ACT = {"identity": _lib.ACT_IDENTITY, "elu": _lib.ACT_ELU, "relu": _lib.ACT_RELU}
+
+
+def _torch_act(x, activation):
+    if activation == "relu":
+        return torch.relu(x)
+    return torch.nn.functional.elu(x) if activation == "elu" else x
+
+
 class TallLinearFn(torch.autograd.Function):
-    """y = x . W^T + b for x [n, f_in] (rows may be strided), W [w, f_in] and b [w] laid out as torch.nn.Linear keeps
-    them: the width-1 convolutions around the brain-network attention step (utils/layers.py:180,183,187,223-224).
-    Forward and input gradient are ordinary GEMMs (torch); the parameter gradients, reductions over the n rows, run on
-    gatmi_linear_bwd_params."""
+    """y = act(x . W^T + b) for x [n, f_in] (rows may be strided), W [w, f_in] and b [w] laid out as torch.nn.Linear
+    keeps them: the width-1 convolutions around the brain-network attention step (tf.layers.conv1d(., w, 1, activation),
+    utils/layers.py:180,183,187,223-224).  The products are ordinary GEMMs (torch; bias and ReLU ride in the GEMM's
+    epilogue); the activation's backward and the bias gradient are one pass (gatmi_bias_act_bwd) and the weight gradient,
+    a reduction over the n rows, runs on gatmi_linear_bwd_params."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, activation):
         _require_cuda(x, W)
-        y = torch.addmm(b, x, W.t()) if b is not None else x @ W.t()
-        ctx.save_for_backward(x, W)
-        ctx.has_bias = b is not None
+        act = _DENSE_ACT[activation]
+        if act == _lib.ACT_IDENTITY:
+            y = torch.addmm(b, x, W.t()) if b is not None else x @ W.t()
+        elif act == _lib.ACT_RELU and b is not None:
+            y = torch._addmm_activation(b, x, W.t(), use_gelu=False)
+        else:
+            pre = x @ W.t()
+            y = torch.empty_like(pre)
+            bb = b if b is not None else torch.zeros(W.shape[0], dtype=pre.dtype, device=pre.device)
+            _lib.call("gatmi_bias_act_fwd", ptr(pre), pre.shape[0], pre.shape[1], pre.stride(0), ptr(bb), act, ptr(y), _lib.current_stream())
+        ctx.save_for_backward(x, W, y if act != _lib.ACT_IDENTITY else None)
+        ctx.has_bias, ctx.act = b is not None, act
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W = ctx.saved_tensors
+        x, W, y = ctx.saved_tensors
         n, f_in = x.shape
         w = W.shape[0]
+        st = _lib.current_stream()
         dy = _f32(dy).contiguous()
+        db = None
+        if ctx.act != _lib.ACT_IDENTITY:                 # through the activation, with the bias gradient in the same pass
+            dpre, db = torch.empty_like(dy), _new((w,), dy)
+            ws = _new((_lib.lib.gatmi_column_sums_ws_floats(n, w),), dy)
+            _lib.call("gatmi_bias_act_bwd", ptr(dy), ptr(y), n, w, w, ctx.act, ptr(dpre), ptr(db), ptr(ws), st)
+            dy = dpre
         dx = dy @ W if ctx.needs_input_grad[0] else None
-        dW = db = None
+        dW = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             if x.stride(1) != 1:
                 x = x.contiguous()
             dWt = _new((f_in, w), dy)
-            db = _new((w,), dy) if ctx.has_bias else None
+            dbl = _new((w,), dy) if (ctx.has_bias and db is None) else None
             ws = _new((_lib.lib.gatmi_linear_bwd_ws_floats(n, f_in, w),), dy)
-            _lib.call("gatmi_linear_bwd_params", ptr(x), n, f_in, x.stride(0), ptr(dy), w, ptr(dWt), ptr(db), ptr(ws), _lib.current_stream())
+            _lib.call("gatmi_linear_bwd_params", ptr(x), n, f_in, x.stride(0), ptr(dy), w, ptr(dWt), ptr(dbl), ptr(ws), st)
             dW = dWt.t()
-        return dx, dW, db
+            db = db if db is not None else dbl
+        return dx, dW, (db if ctx.has_bias else None), None
 
 
 TALL_LINEAR_ROWS = 1024      # below this many rows the layer stays with torch's own backward
 
 
-def tall_linear(x, weight, bias=None):
-    """torch.nn.functional.linear for inputs of many rows and modest widths (x [..., f_in] on the GPU, fp32): same
-    result, parameter gradients from the library's fixed-order reductions."""
-    lead = x.shape[:-1]
+def _rows(x):
     n = 1
-    for d in lead:
+    for d in x.shape[:-1]:
         n *= int(d)
-    if not x.is_cuda or x.dtype != torch.float32 or n < TALL_LINEAR_ROWS or not torch.is_grad_enabled():
-        return torch.nn.functional.linear(x, weight, bias)
+    return n
+
+
+def _tall(x):
+    return x.is_cuda and x.dtype == torch.float32 and _rows(x) >= TALL_LINEAR_ROWS and torch.is_grad_enabled()
+
+
+def tall_linear(x, weight, bias=None, activation="identity"):
+    """act(torch.nn.functional.linear(x, weight, bias)) for inputs of many rows and modest widths (x [..., f_in] on the
+    GPU, fp32; activation "identity", "relu" or "elu"): same result, parameter gradients from the library's fixed-order
+    reductions."""
+    if activation not in _DENSE_ACT:
+        raise ValueError("activation must be 'identity', 'relu' or 'elu', got %r" % (activation,))
+    if not _tall(x):
+        return _torch_act(torch.nn.functional.linear(x, weight, bias), activation)
     if x.dim() == 2:
-        return TallLinearFn.apply(x, weight, bias)
-    return TallLinearFn.apply(x.reshape(n, x.shape[-1]), weight, bias).reshape(*lead, weight.shape[0])
+        return TallLinearFn.apply(x, weight, bias, activation)
+    return TallLinearFn.apply(x.reshape(_rows(x), x.shape[-1]), weight, bias, activation).reshape(*x.shape[:-1], weight.shape[0])
 
 
 class RowBiasFn(torch.autograd.Function):
-    """y = x + b for x [n, w]: the bias of a width-1 convolution (utils/layers.py:180); its gradient, the column
-    sums over the n rows, comes from gatmi_column_sums."""
+    """y = act(x + b) for x [n, w]: bias and activation of a width-1 convolution (utils/layers.py:180) in one pass each
+    way (gatmi_bias_act_fwd / _bwd: the backward forms dy * act'(y) and the bias gradient, its column sums, together)."""
 
     @staticmethod
-    def forward(ctx, x, b):
+    def forward(ctx, x, b, activation):
         _require_cuda(x, b)
-        return x + b
+        act = _DENSE_ACT[activation]
+        y = torch.empty_like(x)
+        _lib.call("gatmi_bias_act_fwd", ptr(x), x.shape[0], x.shape[1], x.stride(0), ptr(b), act, ptr(y), _lib.current_stream())
+        ctx.save_for_backward(y)
+        ctx.act = act
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        db = None
-        if ctx.needs_input_grad[1]:
-            d = _f32(dy)
-            if d.stride(1) != 1:
-                d = d.contiguous()
-            n, w = d.shape
-            db = _new((w,), d)
-            ws = _new((_lib.lib.gatmi_column_sums_ws_floats(n, w),), d)
-            _lib.call("gatmi_column_sums", ptr(d), n, w, d.stride(0), ptr(db), ptr(ws), _lib.current_stream())
-        return dy, db
+        (y,) = ctx.saved_tensors
+        n, w = y.shape
+        d = _f32(dy).contiguous()
+        dpre, db = torch.empty_like(d), _new((w,), d)
+        ws = _new((_lib.lib.gatmi_column_sums_ws_floats(n, w),), d)
+        _lib.call("gatmi_bias_act_bwd", ptr(d), ptr(y), n, w, w, ctx.act, ptr(dpre), ptr(db), ptr(ws), _lib.current_stream())
+        return dpre, db, None
 
 
-def add_row_bias(x, bias):
-    """x [..., w] + bias [w] with the bias gradient from the library's fixed-order column sums (many rows, fp32, GPU);
-    torch's own broadcast add otherwise."""
+def add_row_bias(x, bias, activation="identity"):
+    """act(x [..., w] + bias [w]) with the activation's backward and the bias gradient from one pass of the library
+    (many rows, fp32, GPU, contiguous); torch's own broadcast add and activation otherwise."""
+    if activation not in _DENSE_ACT:
+        raise ValueError("activation must be 'identity', 'relu' or 'elu', got %r" % (activation,))
     w = x.shape[-1]
-    n = x.numel() // max(1, w)
-    if not x.is_cuda or x.dtype != torch.float32 or n < TALL_LINEAR_ROWS or not torch.is_grad_enabled() or not x.is_contiguous():
-        return x + bias
-    return RowBiasFn.apply(x.reshape(n, w), bias.reshape(w)).reshape(x.shape)
+    if not _tall(x) or not x.is_contiguous():
+        return _torch_act(x + bias, activation)
+    return RowBiasFn.apply(x.reshape(_rows(x), w), bias.reshape(w).contiguous(), activation).reshape(x.shape)
 
 
 class InnerProductDecoderFn(torch.autograd.Function):

@@ -180,6 +180,15 @@ int gatmi_linear_bwd_params(const float *X, int64_t n, int32_t f_in, int64_t ldx
 size_t gatmi_column_sums_ws_floats(int64_t n, int32_t w);
 int gatmi_column_sums(const float *Y, int64_t n, int32_t w, int64_t ld, float *out, float *ws, void *stream);
 
+/* Bias and activation of a width-1 convolution over the node rows (tf.layers.conv1d(., w, 1, activation),
+ * utils/layers.py:180,183,223-224): Y = act(X + b), X and Y [n, w] with rows ld floats apart, activation =
+ * GATMI_ACT_IDENTITY / _ELU / _RELU; and its backward from the OUTPUT: dPre = dY * act'(Y), db [w] = column sums of dPre,
+ * in one pass (ws: gatmi_column_sums_ws_floats(n, w) floats). */
+int gatmi_bias_act_fwd(const float *X, int64_t n, int32_t w, int64_t ld, const float *b, int32_t activation,
+                       float *Y, void *stream);
+int gatmi_bias_act_bwd(const float *dY, const float *Y, int64_t n, int32_t w, int64_t ld, int32_t activation,
+                       float *dPre, float *db, float *ws, void *stream);
+
 /* The projection for SPARSE node features: X [n, f_in] in CSR (xrowptr [n+1], xcol, xval in DEVICE
  * memory), as the sparse tuple of preprocess_features (utils/process.py:155-162, the second return
  * value) describes it; Cora's features are 98.7 % zeros.  Wh = X . W summed over stored entries

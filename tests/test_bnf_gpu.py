@@ -123,49 +123,60 @@ def test_gat_ae_bnf_v2_model_runs_on_the_kernels():
     assert not missing, missing
 
 
-@pytest.mark.parametrize("n,f_in,w,strided", [(5000, 384, 64, False), (4500, 16, 16, False), (12300, 64, 64, True), (3000, 1, 64, False),
-                                               (2500, 320, 64, False), (2048, 128, 256, False), (1500, 10, 6, False), (1100, 64, 7, True)])
-def test_tall_linear_matches_the_plain_dense_layer(n, f_in, w, strided):
+@pytest.mark.parametrize("n,f_in,w,strided,activation", [(5000, 384, 64, False, "relu"), (4500, 16, 16, False, "identity"), (12300, 64, 64, True, "relu"),
+                                                          (3000, 1, 64, False, "identity"), (2500, 320, 64, False, "elu"), (2048, 128, 256, False, "relu"),
+                                                          (1500, 10, 6, False, "relu"), (1100, 64, 7, True, "elu")])
+def test_tall_linear_matches_the_plain_dense_layer(n, f_in, w, strided, activation):
     """The width-1 convolutions of utils/layers.py:180,183,187,223-224 as a dense layer over all node rows: output
-    and input gradient are torch's GEMMs, weight and bias gradients come from the library's reductions over the rows;
-    all against a float64 evaluation."""
+    and input gradient are torch's GEMMs, the activation's backward, the bias gradient and the weight gradient come from
+    the library's passes over the rows; all against a float64 evaluation."""
     from gat_amd import ops
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(n + f_in + w)
+    act = {"relu": torch.relu, "elu": torch.nn.functional.elu, "identity": lambda t: t}[activation]
     x64 = torch.tensor(rng.normal(0, 1, (n, 3 * f_in if strided else f_in)), requires_grad=True)
     W64 = torch.tensor(rng.normal(0, 0.3, (w, f_in)), requires_grad=True)
     b64 = torch.tensor(rng.normal(0, 0.3, w), requires_grad=True)
     dy = torch.tensor(rng.normal(0, 1, (n, w)))
     xs64 = x64[:, f_in:2 * f_in] if strided else x64
-    (torch.nn.functional.linear(xs64, W64, b64) * dy).sum().backward()
+    ref = act(torch.nn.functional.linear(xs64, W64, b64))
+    (ref * dy).sum().backward()
     x = x64.detach().to(dev, torch.float32).requires_grad_(True)
     W = W64.detach().to(dev, torch.float32).requires_grad_(True)
     b = b64.detach().to(dev, torch.float32).requires_grad_(True)
     xs = x[:, f_in:2 * f_in] if strided else x
-    y = ops.tall_linear(xs, W, b)
+    y = ops.tall_linear(xs, W, b, activation)
     assert y.grad_fn is not None and "TallLinearFn" in type(y.grad_fn).__name__
-    assert_close(y.detach().cpu().numpy(), torch.nn.functional.linear(xs64, W64, b64).detach().numpy(), what="tall linear forward")
+    assert_close(y.detach().cpu().numpy(), ref.detach().numpy(), what="tall linear forward")
+    # an output within fp32 rounding of the ReLU's kink may fall on the other side of it than in float64
+    clear = (ref.detach().abs() > 1e-5) if activation == "relu" else torch.ones_like(ref, dtype=torch.bool)
+    assert bool(((y.detach().cpu() > 0) == (ref.detach() > 0))[clear].all())
     y.backward(dy.to(dev, torch.float32))
-    assert_close(W.grad.cpu().numpy(), W64.grad.numpy(), what="tall linear dW")
-    assert_close(b.grad.cpu().numpy(), b64.grad.numpy(), what="tall linear db")
-    assert_close(x.grad.cpu().numpy(), x64.grad.numpy(), what="tall linear dX")
+    assert_close(W.grad.cpu().numpy(), W64.grad.numpy(), rtol=2e-5, atol_scale=1e-5, what="tall linear dW")
+    assert_close(b.grad.cpu().numpy(), b64.grad.numpy(), rtol=2e-5, atol_scale=1e-5, what="tall linear db")
+    assert_close(x.grad.cpu().numpy(), x64.grad.numpy(), rtol=2e-5, atol_scale=1e-5, what="tall linear dX")
     # without a bias, and below the row limit the layer is torch's own
-    y2 = ops.tall_linear(xs, W)
+    y2 = ops.tall_linear(xs, W, None, activation)
+    assert_close(y2.detach().cpu().numpy(), act(torch.nn.functional.linear(xs64, W64)).detach().numpy(), what="tall linear forward, no bias")
     y2.backward(dy.to(dev, torch.float32))
-    assert ops.tall_linear(xs[:100], W, b).grad_fn is not None and "TallLinearFn" not in type(ops.tall_linear(xs[:100], W, b).grad_fn).__name__
+    small = ops.tall_linear(xs[:100], W, b, activation)
+    assert small.grad_fn is not None and "TallLinearFn" not in type(small.grad_fn).__name__
+    assert_close(small.detach().cpu().numpy(), ref[:100].detach().numpy(), what="small linear forward")
 
 
-@pytest.mark.parametrize("shape", [(50, 246, 384), (3, 1000, 7), (2048, 64)])
-def test_row_bias_gradient_is_the_column_sum(shape):
+@pytest.mark.parametrize("shape,activation", [((50, 246, 384), "relu"), ((3, 1000, 7), "elu"), ((2048, 64), "identity")])
+def test_row_bias_and_activation(shape, activation):
     from gat_amd import ops
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(shape[-1])
+    act = {"relu": torch.relu, "elu": torch.nn.functional.elu, "identity": lambda t: t}[activation]
     x64, b64, dy = torch.tensor(rng.normal(0, 1, shape), requires_grad=True), torch.tensor(rng.normal(0, 1, shape[-1]), requires_grad=True), torch.tensor(rng.normal(0, 1, shape))
-    ((x64 + b64) * dy).sum().backward()
+    ref = act(x64 + b64)
+    (ref * dy).sum().backward()
     x = x64.detach().to(dev, torch.float32).requires_grad_(True)
     b = b64.detach().to(dev, torch.float32).requires_grad_(True)
-    y = ops.add_row_bias(x, b)
-    assert torch.equal(y, x + b)
+    y = ops.add_row_bias(x, b, activation)
+    assert_close(y.detach().cpu().numpy(), ref.detach().numpy(), what="row bias forward")
     y.backward(dy.to(dev, torch.float32))
-    assert_close(b.grad.cpu().numpy(), b64.grad.numpy(), what="row bias db")
-    assert torch.equal(x.grad, dy.to(dev, torch.float32))
+    assert_close(b.grad.cpu().numpy(), b64.grad.numpy(), rtol=2e-5, atol_scale=1e-5, what="row bias db")
+    assert_close(x.grad.cpu().numpy(), x64.grad.numpy(), rtol=2e-5, atol_scale=1e-5, what="row bias dX")
