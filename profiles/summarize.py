@@ -41,7 +41,10 @@ def kernel_key(name):
 def counters(dirs):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in dirs:
-        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        # gpurun merges a call's outputs into the local directory without removing what an earlier call left there:
+        # of several runs of one pass only the newest file counts
+        found = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+        for f in found[-1:]:
             for r in csv.DictReader(open(f)):
                 if "gatmi" not in r["Kernel_Name"]:
                     continue
@@ -65,9 +68,9 @@ def write_summary(acc, path, header):
 
 
 def copy_stats(src_dir, dst):
-    files = glob.glob(os.path.join(src_dir, "**", "*kernel_stats.csv"), recursive=True)
+    files = sorted(glob.glob(os.path.join(src_dir, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if files:
-        shutil.copy(files[0], dst)
+        shutil.copy(files[-1], dst)                # the newest run of the part (see counters)
         return True
     return False
 
