@@ -12,7 +12,7 @@ graphs differ in the strength of one block of connections; the node feature is t
 --replay: at the reference's batch of 50 a step is several hundred launches of a few microseconds each and the host
 issuing them sets the pace; captured once (gat_amd.graphs.capture, Adam with its step count on the device) and
 replayed on fresh data copied into the captured input tensors, the same step takes 3.1 ms instead of ≈ 9 ms (600 steps,
-same loss curve; at the reference's sizes, second line above, 6.9 ms replayed and 10-13 ms eager).  The loop issues some twenty launches per step to draw its batch; gat_amd is imported before the first GPU
+same loss curve; at the reference's sizes, second line above, 6.8 ms replayed and 10-13 ms eager).  The loop issues some twenty launches per step to draw its batch; gat_amd is imported before the first GPU
 call so that the replay stays right through thousands of them (gat_amd/_hip_env.py).
 """
 import argparse
