@@ -712,8 +712,8 @@ class TallLinearFn(torch.autograd.Function):
         act = _DENSE_ACT[activation]
         if act == _lib.ACT_IDENTITY:
             y = torch.addmm(b, x, W.t()) if b is not None else x @ W.t()
-        elif act == _lib.ACT_RELU and b is not None:
-            y = torch._addmm_activation(b, x, W.t(), use_gelu=False)
+        elif act == _lib.ACT_RELU and b is not None and hasattr(torch, "_addmm_activation"):
+            y = torch._addmm_activation(b, x, W.t(), use_gelu=False)      # bias and ReLU in the GEMM's epilogue
         else:
             pre = x @ W.t()
             y = torch.empty_like(pre)
